@@ -1,0 +1,119 @@
+"""ctypes binding of libndmps_hip.so (C ABI declared in include/ndmps_hip.h).
+
+The library is looked up in-tree only (next to this file); it is built by
+``__graft_entry__.build()`` / ``make -C img-compression-mps_amd/csrc``.  A missing library
+is a hard error -- there is no fallback path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libndmps_hip.so")
+
+OK, EINVAL, EHIP, ENOCONV, EWORKSPACE = 0, -1, -2, -3, -4
+
+i64 = C.c_int64
+p_i64 = C.POINTER(C.c_int64)
+p_f64 = C.POINTER(C.c_double)
+p_f32 = C.POINTER(C.c_float)
+p_int = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/ndmps_hip.h declares
+SIGNATURES = {
+    "ndmps_version": (C.c_int, []),
+    "ndmps_last_error": (C.c_char_p, []),
+    "ndmps_device_count": (C.c_int, []),
+    "ndmps_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, p_i64, C.c_int, p_i64]),
+    "ndmps_plan_destroy": (C.c_int, [vp]),
+    "ndmps_plan_numel": (i64, [vp]),
+    "ndmps_plan_is_tiled": (C.c_int, [vp]),
+    "ndmps_plan_emulate": (C.c_int, [C.c_int, p_i64, C.c_int, p_i64, C.c_int, p_i64]),
+    "ndmps_encode_permute": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "ndmps_decode_permute": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "ndmps_encode_permute_generic": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "ndmps_decode_permute_generic": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "ndmps_dct_basis_f32": (C.c_int, [vp, i64, vp]),
+    "ndmps_dct_last_f32": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ndmps_idct_last_f32": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ndmps_sumsq_f32": (C.c_int, [vp, i64, p_f64, vp, i64, vp]),
+    "ndmps_minmax_f32": (C.c_int, [vp, i64, p_f32, p_f32, vp, i64, vp]),
+    "ndmps_scale_f32": (C.c_int, [vp, i64, C.c_double, vp]),
+    "ndmps_reduce_workspace_bytes": (i64, []),
+    "ndmps_sgemm": (C.c_int, [C.c_int, C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp]),
+    "ndmps_dgemm": (C.c_int, [C.c_int, C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp]),
+    "ndmps_gram_workspace_bytes": (i64, [i64, i64]),
+    "ndmps_gram_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, i64, vp]),
+    "ndmps_syevj_workspace_bytes": (i64, [i64]),
+    "ndmps_syevj_f64": (C.c_int, [vp, i64, vp, vp, vp, i64, p_int, vp]),
+    "ndmps_tt_layout": (C.c_int, [C.c_int, p_i64, i64, p_i64, p_i64, p_i64, p_i64]),
+    "ndmps_tt_sweep_f32": (C.c_int, [vp, C.c_int, p_i64, C.c_double, i64, vp, p_i64, p_i64, p_f64,
+                                     p_i64, vp, i64, vp]),
+    "ndmps_compress_bond_workspace_bytes": (i64, [i64, i64, i64, i64, i64]),
+    "ndmps_compress_bond_f32": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, C.c_double, i64, vp, vp,
+                                          p_i64, p_f64, vp, i64, vp]),
+    "ndmps_chain_workspace_bytes": (i64, [C.c_int, p_i64, p_i64]),
+    "ndmps_chain_contract_f32": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), vp, vp, i64, vp]),
+    "ndmps_overlap_workspace_bytes": (i64, [C.c_int, p_i64, p_i64, p_i64]),
+    "ndmps_overlap_f32": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), p_i64, C.POINTER(vp), p_f64,
+                                    vp, i64, vp]),
+    "ndmps_quantize_f32": (C.c_int, [vp, i64, C.c_float, C.c_float, C.c_int, vp, vp]),
+    "ndmps_dequantize_f32": (C.c_int, [vp, i64, C.c_float, C.c_float, C.c_int, vp, vp]),
+}
+
+_lib = None
+
+
+class NdmpsHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libndmps_hip.so (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C img-compression-mps_amd/csrc`.  There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the binding drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map a return code to the exception the reference would raise (Errors)."""
+    if rc >= 0:
+        return rc
+    msg = load().ndmps_last_error().decode("utf-8", "replace")
+    if rc == EINVAL:
+        raise ValueError(msg)
+    raise NdmpsHipError(f"libndmps_hip error {rc}: {msg}")
+
+
+def i64_array(values):
+    arr = (C.c_int64 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+def require_device():
+    """Fail loudly when there is no HIP device (the product never computes on the CPU)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "imgcompressionmps_amd needs an AMD GPU (HIP device); none is visible and there is no CPU path."
+        )
+    load()
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,64 @@
+// Shared host-side helpers for libndmps_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ndmps_hip.h"
+
+namespace ndmps {
+
+void set_error(const char* fmt, ...);
+
+#define NDMPS_CHECK_HIP(expr)                                                        \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      ndmps::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                       __FILE__, __LINE__);                                          \
+      return NDMPS_EHIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+#define NDMPS_REQUIRE(cond, ...)                                                     \
+  do {                                                                               \
+    if (!(cond)) {                                                                   \
+      ndmps::set_error(__VA_ARGS__);                                                 \
+      return NDMPS_EINVAL;                                                           \
+    }                                                                                \
+  } while (0)
+
+#define NDMPS_TRY(expr)                                                              \
+  do {                                                                               \
+    int _r = (expr);                                                                 \
+    if (_r != NDMPS_OK) return _r;                                                   \
+  } while (0)
+
+#define NDMPS_LAUNCH_CHECK() NDMPS_CHECK_HIP(hipGetLastError())
+
+static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline int64_t ceil_div(int64_t x, int64_t a) { return (x + a - 1) / a; }
+
+// bump allocator over a caller-provided device workspace (256-byte aligned pieces)
+struct Arena {
+  char* base;
+  int64_t size;
+  int64_t used;
+  Arena(void* p, int64_t n) : base((char*)p), size(n), used(0) {}
+  template <typename T>
+  T* take(int64_t count) {
+    int64_t off = round_up(used, 256);
+    int64_t end = off + (int64_t)sizeof(T) * count;
+    used = end;
+    if (end > size || base == nullptr) return nullptr;
+    return (T*)(base + off);
+  }
+};
+static inline int64_t arena_bytes(int64_t used, int64_t elem, int64_t count) {
+  return round_up(used, 256) + elem * count;
+}
+
+constexpr int kNumCU = 256;  // MI355X
+
+}  // namespace ndmps

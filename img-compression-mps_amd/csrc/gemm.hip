@@ -1,0 +1,376 @@
+// Dense building blocks on the CDNA4 matrix cores.
+//
+//   ndmps_sgemm  : C = op(A) op(B), fp32 in / fp32 accumulate, v_mfma_f32_32x32x2_f32
+//   ndmps_dgemm  : same in fp64, v_mfma_f64_16x16x4_f64
+//   ndmps_gram_f32 : G = A^T A with fp32 A and fp64 products/accumulation (exact products,
+//                  one rounding per add) -- the small-side Gram of the per-site SVD.
+//
+// They stand in for the LAPACK/BLAS calls NumPy makes inside quimb for the reference
+// (dgemm via tensordot in `mps ^ ...`, core/ndmps.py:140; the SVD's internal products in
+// from_dense, core/ndmps.py:74).  GEMMs here are genuine dense GEMMs (bond x bond x phys);
+// nothing is reshaped to reach the matrix cores.
+//
+// Layout notes (wave64): for the f32 32x32x2 MFMA lane l feeds A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; for the f64 16x16x4 MFMA A[i=l&15][k=l>>4], B[k=l>>4][j=l&15].  Both
+// operand tiles are therefore staged k-major in LDS (As[k][m], Bs[k][n]) so a fragment
+// read is 32 (16) consecutive words per half (quarter) wave: conflict-free ds_read.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<float> {
+  static constexpr int MT = 32;   // tile edge
+  static constexpr int KS = 2;    // k per instruction
+  static constexpr int NACC = 16; // accumulator registers per lane
+  typedef f32x16 acc_t;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int acc_row(int reg, int lane) {
+    return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+  }
+  static __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
+  static __device__ __forceinline__ int frag_idx(int lane) { return lane & 31; }
+  static __device__ __forceinline__ int frag_k(int lane) { return lane >> 5; }
+};
+
+template <>
+struct Mfma<double> {
+  static constexpr int MT = 16;
+  static constexpr int KS = 4;
+  static constexpr int NACC = 4;
+  typedef f64x4 acc_t;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int acc_row(int reg, int lane) { return (lane >> 4) + 4 * reg; }
+  static __device__ __forceinline__ int acc_col(int lane) { return lane & 15; }
+  static __device__ __forceinline__ int frag_idx(int lane) { return lane & 15; }
+  static __device__ __forceinline__ int frag_k(int lane) { return lane >> 4; }
+};
+
+// ----------------------------------------------------------------------------------
+// Generic tiled GEMM.  256 threads = 4 waves laid out WAVES_M x WAVES_N over a BM x BN
+// block tile; BK-deep k-tiles staged through LDS (k-major for both operands).
+// ----------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+__global__ void __launch_bounds__(256)
+gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
+            const T* __restrict__ B, int64_t ldb, T* __restrict__ C, int64_t ldc) {
+  using MF = Mfma<T>;
+  constexpr int BK = 16;
+  constexpr int MT = MF::MT;
+  constexpr int TM = BM / (WAVES_M * MT);
+  constexpr int TN = BN / (WAVES_N * MT);
+  constexpr int PAD = 4;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(TM >= 1 && TN >= 1, "tile too small");
+
+  __shared__ T As[BK][BM + PAD];
+  __shared__ T Bs[BK][BN + PAD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;  // x: row blocks (can exceed 65535)
+  const int64_t n0 = (int64_t)blockIdx.y * BN;
+
+  typename MF::acc_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = (T)0;
+
+  for (int64_t k0 = 0; k0 < K; k0 += BK) {
+    // ---- stage A tile: As[k][m] = op(A)[m0+m][k0+k]
+    if (TA) {  // stored (K, M): contiguous along m
+      for (int e = tid; e < BK * BM; e += 256) {
+        const int k = e / BM, m = e % BM;
+        const int64_t gk = k0 + k, gm = m0 + m;
+        As[k][m] = (gk < K && gm < M) ? A[gk * lda + gm] : (T)0;
+      }
+    } else {  // stored (M, K): contiguous along k
+      for (int e = tid; e < BK * BM; e += 256) {
+        const int m = e / BK, k = e % BK;
+        const int64_t gk = k0 + k, gm = m0 + m;
+        As[k][m] = (gk < K && gm < M) ? A[gm * lda + gk] : (T)0;
+      }
+    }
+    // ---- stage B tile: Bs[k][n] = op(B)[k0+k][n0+n]
+    if (TB) {  // stored (N, K): contiguous along k
+      for (int e = tid; e < BK * BN; e += 256) {
+        const int n = e / BK, k = e % BK;
+        const int64_t gk = k0 + k, gn = n0 + n;
+        Bs[k][n] = (gk < K && gn < N) ? B[gn * ldb + gk] : (T)0;
+      }
+    } else {  // stored (K, N): contiguous along n
+      for (int e = tid; e < BK * BN; e += 256) {
+        const int k = e / BN, n = e % BN;
+        const int64_t gk = k0 + k, gn = n0 + n;
+        Bs[k][n] = (gk < K && gn < N) ? B[gk * ldb + gn] : (T)0;
+      }
+    }
+    __syncthreads();
+
+    const int fi = MF::frag_idx(lane);
+    const int fk = MF::frag_k(lane);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += MF::KS) {
+      T a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kk + fk][(wm * TM + i) * MT + fi];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kk + fk][(wn * TN + j) * MT + fi];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + (wn * TN + j) * MT + MF::acc_col(lane);
+#pragma unroll
+      for (int r = 0; r < MF::NACC; ++r) {
+        const int64_t row = m0 + (wm * TM + i) * MT + MF::acc_row(r, lane);
+        if (row < M && col < N) C[row * ldc + col] = acc[i][j][r];
+      }
+    }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_gemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const T* A, int64_t lda,
+                const T* B, int64_t ldb, T* C, int64_t ldc, hipStream_t stream) {
+  dim3 grid((unsigned)ndmps::ceil_div(m, BM), (unsigned)ndmps::ceil_div(n, BN));
+  dim3 block(256);
+#define NDMPS_GEMM_LAUNCH(TA_, TB_)                                                             \
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TA_, TB_>), grid, block, 0, stream, \
+                     m, n, k, A, lda, B, ldb, C, ldc)
+  if (transA && transB) NDMPS_GEMM_LAUNCH(true, true);
+  else if (transA) NDMPS_GEMM_LAUNCH(true, false);
+  else if (transB) NDMPS_GEMM_LAUNCH(false, true);
+  else NDMPS_GEMM_LAUNCH(false, false);
+#undef NDMPS_GEMM_LAUNCH
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+template <typename T>
+int gemm_check(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, int transA, const T* B,
+               int64_t ldb, int transB, T* C, int64_t ldc) {
+  NDMPS_REQUIRE(m >= 0 && n >= 0 && k >= 0, "negative GEMM extent");
+  NDMPS_REQUIRE(A && B && C, "NULL GEMM operand");
+  NDMPS_REQUIRE(lda >= (transA ? m : k) && ldb >= (transB ? k : n) && ldc >= n,
+                "leading dimension too small (lda=%lld ldb=%lld ldc=%lld)", (long long)lda,
+                (long long)ldb, (long long)ldc);
+  NDMPS_REQUIRE(ndmps::ceil_div(n, 16) < 65536, "GEMM n=%lld exceeds grid.y", (long long)n);
+  NDMPS_REQUIRE(ndmps::ceil_div(m, 32) < 2147483647LL, "GEMM m=%lld exceeds grid.x", (long long)m);
+  return NDMPS_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// Gram matrix G = A^T A, A (m, n) fp32 row-major, G fp64.
+// Lane l of a wave reads A[r + (l>>4)][c + (l&15)] -- straight row-major segments, no
+// transposition -- converts to f64 and feeds v_mfma_f64_16x16x4_f64 as both operands.
+// A workgroup owns one (T*16)^2 tile of the upper triangle over a slab of rows; its 4
+// waves interleave 4-row k-steps and fold their accumulators through LDS; the slab result
+// goes to a partial buffer, reduced in fixed order (deterministic) by gram_reduce_kernel.
+// ----------------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(256)
+gram_partial_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+                    double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab) {
+  constexpr int TS = 16 * T;  // tile edge
+  __shared__ double red[TS][TS + 1];
+
+  // decode upper-triangular tile index
+  int tile = blockIdx.x, ti = 0;
+  while (tile >= n_tiles_1d - ti) {
+    tile -= n_tiles_1d - ti;
+    ++ti;
+  }
+  const int tj = ti + tile;
+  const int64_t i0 = (int64_t)ti * TS, j0 = (int64_t)tj * TS;
+  const int64_t slab = blockIdx.y;
+  const int64_t r_begin = slab * rows_per_slab;
+  const int64_t r_end = min(m, r_begin + rows_per_slab);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane >> 4, lc = lane & 15;
+
+  f64x4 acc[T][T];
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  for (int64_t r = r_begin + 4 * wave; r < r_end; r += 16) {
+    const int64_t row = r + lr;
+    const bool row_ok = row < r_end;
+    double av[T], bv[T];
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+      const int64_t ca = i0 + 16 * a + lc;
+      const int64_t cb = j0 + 16 * a + lc;
+      av[a] = (row_ok && ca < n) ? (double)A[row * lda + ca] : 0.0;
+      bv[a] = (row_ok && cb < n) ? (double)A[row * lda + cb] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+      for (int b = 0; b < T; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+  }
+
+  // fold the 4 waves through LDS, one after the other (fixed order)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int rr = 16 * a + lr + 4 * reg, cc = 16 * b + lc;
+            if (w == 0) red[rr][cc] = acc[a][b][reg];
+            else red[rr][cc] += acc[a][b][reg];
+          }
+    }
+    __syncthreads();
+  }
+  double* out = partial + ((int64_t)slab * gridDim.x + blockIdx.x) * (TS * TS);
+  for (int e = tid; e < TS * TS; e += 256) out[e] = red[e / TS][e % TS];
+}
+
+template <int T>
+__global__ void __launch_bounds__(256)
+gram_reduce_kernel(const double* __restrict__ partial, double* __restrict__ G, int64_t n,
+                   int n_tiles_1d, int n_tiles, int n_slabs) {
+  constexpr int TS = 16 * T;
+  int tile = blockIdx.x, ti = 0;
+  while (tile >= n_tiles_1d - ti) {
+    tile -= n_tiles_1d - ti;
+    ++ti;
+  }
+  const int tj = ti + tile;
+  for (int e = threadIdx.x; e < TS * TS; e += 256) {
+    double s = 0.0;
+    for (int sl = 0; sl < n_slabs; ++sl)
+      s += partial[((int64_t)sl * n_tiles + blockIdx.x) * (TS * TS) + e];
+    const int64_t r = (int64_t)ti * TS + e / TS, c = (int64_t)tj * TS + e % TS;
+    if (r < n && c < n) {
+      if (ti == tj) {
+        if (c >= r) {  // keep the diagonal tile exactly symmetric
+          G[r * n + c] = s;
+          G[c * n + r] = s;
+        }
+      } else {
+        G[r * n + c] = s;
+        G[c * n + r] = s;
+      }
+    }
+  }
+}
+
+struct GramGeom {
+  int T;          // 16-wide sub-tiles per tile edge
+  int tiles_1d;
+  int n_tiles;    // upper triangle incl. diagonal
+  int n_slabs;
+  int64_t rows_per_slab;
+};
+
+GramGeom gram_geometry(int64_t m, int64_t n) {
+  GramGeom g;
+  g.T = n <= 16 ? 1 : (n <= 32 ? 2 : 4);
+  const int ts = 16 * g.T;
+  g.tiles_1d = (int)ndmps::ceil_div(n, ts);
+  g.n_tiles = g.tiles_1d * (g.tiles_1d + 1) / 2;
+  // aim at ~4 workgroups per CU; every slab is a multiple of 16 rows (4 waves x 4 rows)
+  int64_t want = std::max<int64_t>(1, (4 * ndmps::kNumCU) / g.n_tiles);
+  int64_t rows = ndmps::round_up(std::max<int64_t>(ndmps::ceil_div(m, want), 64), 16);
+  g.rows_per_slab = rows;
+  g.n_slabs = (int)std::max<int64_t>(1, ndmps::ceil_div(m, rows));
+  return g;
+}
+
+}  // namespace
+
+extern "C" int ndmps_sgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const float* d_A,
+                           int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+                           ndmps_stream_t stream) {
+  NDMPS_TRY(gemm_check(m, n, k, d_A, lda, transA, d_B, ldb, transB, d_C, ldc));
+  if (m == 0 || n == 0) return NDMPS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 32) return launch_gemm<float, 128, 32, 4, 1>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
+  if (n <= 64 || m <= 64)
+    return launch_gemm<float, 64, 64, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
+  return launch_gemm<float, 128, 128, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
+}
+
+extern "C" int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const double* d_A,
+                           int64_t lda, const double* d_B, int64_t ldb, double* d_C, int64_t ldc,
+                           ndmps_stream_t stream) {
+  NDMPS_TRY(gemm_check(m, n, k, d_A, lda, transA, d_B, ldb, transB, d_C, ldc));
+  if (m == 0 || n == 0) return NDMPS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 16) return launch_gemm<double, 64, 16, 4, 1>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
+  if (n <= 32 || m <= 32)
+    return launch_gemm<double, 32, 32, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
+  return launch_gemm<double, 64, 64, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
+}
+
+extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
+  if (m <= 0 || n <= 0) return 0;
+  GramGeom g = gram_geometry(m, n);
+  const int ts = 16 * g.T;
+  return (int64_t)g.n_slabs * g.n_tiles * ts * ts * (int64_t)sizeof(double) + 256;
+}
+
+extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
+                              void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_A && d_G, "NULL Gram operand");
+  NDMPS_REQUIRE(m > 0 && n > 0 && lda >= n, "bad Gram extents m=%lld n=%lld lda=%lld", (long long)m,
+                (long long)n, (long long)lda);
+  if (ws_bytes < ndmps_gram_workspace_bytes(m, n) || d_ws == nullptr) {
+    ndmps::set_error("Gram workspace too small: %lld < %lld", (long long)ws_bytes,
+                     (long long)ndmps_gram_workspace_bytes(m, n));
+    return NDMPS_EWORKSPACE;
+  }
+  GramGeom g = gram_geometry(m, n);
+  NDMPS_REQUIRE(g.n_slabs < 65536, "Gram slab count %d exceeds grid.y", g.n_slabs);
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = (double*)d_ws;
+  dim3 grid(g.n_tiles, g.n_slabs);
+#define NDMPS_GRAM(TT)                                                                              \
+  do {                                                                                              \
+    hipLaunchKernelGGL(gram_partial_kernel<TT>, grid, dim3(256), 0, s, d_A, m, n, lda, partial,     \
+                       g.tiles_1d, g.rows_per_slab);                                                \
+    hipLaunchKernelGGL(gram_reduce_kernel<TT>, dim3(g.n_tiles), dim3(256), 0, s, partial, d_G, n,   \
+                       g.tiles_1d, g.n_tiles, g.n_slabs);                                           \
+  } while (0)
+  if (g.T == 1) NDMPS_GRAM(1);
+  else if (g.T == 2) NDMPS_GRAM(2);
+  else NDMPS_GRAM(4);
+#undef NDMPS_GRAM
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}

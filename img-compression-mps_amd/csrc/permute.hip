@@ -1,0 +1,428 @@
+// Index permutation between C-order `shape` and C-order site dims (d_0..d_{L-1}).
+//
+// Replaces the reference's materialised (L,*shape) int64 encoding map
+// (utils/core.py:6-35,129-168) and the NumPy fancy-index scatter / gather through it
+// (core/ndmps.py:66-71, :144-148).  No map is ever materialised: the flat destination of
+// a voxel is additive over dimensions, dest(x) = sum_j T_j[x_j], and the flat source of a
+// site-order element is additive over sites, src(i_0..i_{L-1}) = sum_l S_l[i_l]; the plan
+// holds those small tables (host-built from factor_arr with exact int64 arithmetic).
+//
+// Two kernel families:
+//   generic : one thread per OUTPUT element, table-summed gather (any plan).
+//   tiled   : the lowest sites (<= 8192 elements) form a tile that is contiguous in site
+//             order; a workgroup stages one tile in LDS, reading the source in ascending
+//             source-address order (sorted table, so HBM reads come in whole runs along
+//             the last axis) and writing site order linearly (and the mirror for decode).
+//             HBM-bound: 1 read + 1 write of every element, nothing else.
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxDim = 8;
+constexpr int kMaxSites = 64;
+constexpr int kMaxGroups = 16;
+constexpr int64_t kGroupCap = 4096;  // table entries per high group
+constexpr int64_t kTileCap = 8192;   // elements per LDS tile (lowest group)
+constexpr int64_t kTileMin = 256;
+
+struct DevPlan {
+  int ndim;
+  int n_groups;  // groups of consecutive sites, [0] most significant
+  int64_t numel;
+  int64_t shape[kMaxDim];
+  int64_t group_size[kMaxGroups];
+  const int64_t* group_tab[kMaxGroups];  // src offset contribution per group index
+  const int64_t* dim_tab[kMaxDim];       // dest offset contribution per coordinate
+  // tiled path: tile = lowest group
+  int64_t tile;               // elements per tile
+  const uint32_t* order;      // [tile] site-order position of the k-th smallest source offset
+  const int64_t* src_sorted;  // [tile] that source offset
+};
+
+}  // namespace
+
+// host image of every table (also used by ndmps_plan_emulate, which needs no GPU)
+struct HostTables {
+  std::vector<std::vector<int64_t>> dim_tab;
+  std::vector<std::vector<int64_t>> group_tab;
+  std::vector<uint32_t> order;
+  std::vector<int64_t> src_sorted;
+};
+
+struct ndmps_plan {
+  DevPlan dev;
+  HostTables host;
+  int tiled;
+  int L;
+  std::vector<void*> allocations;
+};
+
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256) encode_generic_kernel(DevPlan p, const T* __restrict__ src,
+                                                              T* __restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < p.numel; o += stride) {
+    int64_t rem = o, off = 0;
+    for (int g = p.n_groups - 1; g >= 0; --g) {
+      const int64_t gs = p.group_size[g];
+      const int64_t q = rem / gs;
+      off += p.group_tab[g][rem - q * gs];
+      rem = q;
+    }
+    dst[o] = src[off];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) decode_generic_kernel(DevPlan p, const T* __restrict__ dense,
+                                                              T* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < p.numel; f += stride) {
+    int64_t rem = f, off = 0;
+    for (int j = p.ndim - 1; j >= 0; --j) {
+      const int64_t n = p.shape[j];
+      const int64_t q = rem / n;
+      off += p.dim_tab[j][rem - q * n];
+      rem = q;
+    }
+    out[f] = dense[off];
+  }
+}
+
+__device__ __forceinline__ int64_t tile_source_base(const DevPlan& p, int64_t tile_idx) {
+  int64_t rem = tile_idx, off = 0;
+  for (int g = p.n_groups - 2; g >= 0; --g) {
+    const int64_t gs = p.group_size[g];
+    const int64_t q = rem / gs;
+    off += p.group_tab[g][rem - q * gs];
+    rem = q;
+  }
+  return off;
+}
+
+// One workgroup per tile (grid-stride).  LDS holds the tile in site order.
+template <typename T>
+__global__ void __launch_bounds__(256) encode_tiled_kernel(DevPlan p, const T* __restrict__ src,
+                                                           T* __restrict__ dst, int64_t n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  const int tile = (int)p.tile;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const T* s = src + tile_source_base(p, t);
+    for (int k = threadIdx.x; k < tile; k += 256) lds[p.order[k]] = s[p.src_sorted[k]];
+    __syncthreads();
+    T* d = dst + t * tile;
+    for (int k = threadIdx.x; k < tile; k += 256) d[k] = lds[k];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) decode_tiled_kernel(DevPlan p, const T* __restrict__ dense,
+                                                           T* __restrict__ out, int64_t n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  const int tile = (int)p.tile;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const T* d = dense + t * tile;
+    for (int k = threadIdx.x; k < tile; k += 256) lds[k] = d[k];
+    __syncthreads();
+    T* o = out + tile_source_base(p, t);
+    for (int k = threadIdx.x; k < tile; k += 256) o[p.src_sorted[k]] = lds[p.order[k]];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+int upload(ndmps_plan* plan, const std::vector<T>& host, const T** dev_out) {
+  void* d = nullptr;
+  if (dev_out == nullptr) return NDMPS_OK;
+  NDMPS_CHECK_HIP(hipMalloc(&d, std::max<size_t>(host.size(), 1) * sizeof(T)));
+  plan->allocations.push_back(d);
+  if (!host.empty())
+    NDMPS_CHECK_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dev_out = (const T*)d;
+  return NDMPS_OK;
+}
+
+int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L, const int64_t* f) {
+  DevPlan& dp = plan->dev;
+  dp.ndim = ndim;
+  plan->L = L;
+  int64_t numel = 1;
+  for (int j = 0; j < ndim; ++j) {
+    NDMPS_REQUIRE(shape[j] > 0, "shape[%d]=%lld must be positive", j, (long long)shape[j]);
+    int64_t prod = 1;
+    for (int l = 0; l < L; ++l) {
+      NDMPS_REQUIRE(f[l * ndim + j] > 0, "factor_arr[%d][%d] must be positive", l, j);
+      prod *= f[l * ndim + j];
+    }
+    NDMPS_REQUIRE(prod == shape[j], "factor_arr column %d multiplies to %lld, shape is %lld", j,
+                  (long long)prod, (long long)shape[j]);
+    dp.shape[j] = shape[j];
+    numel *= shape[j];
+  }
+  dp.numel = numel;
+
+  // strides
+  std::vector<int64_t> src_stride(ndim, 1), site_dim(L, 1), site_stride(L, 1);
+  for (int j = ndim - 2; j >= 0; --j) src_stride[j] = src_stride[j + 1] * shape[j + 1];
+  for (int l = 0; l < L; ++l)
+    for (int j = 0; j < ndim; ++j) site_dim[l] *= f[l * ndim + j];
+  for (int l = L - 2; l >= 0; --l) site_stride[l] = site_stride[l + 1] * site_dim[l + 1];
+  // w[l][j]: weight of digit (l, j) inside coordinate x_j = product of later radices
+  std::vector<int64_t> w((size_t)L * ndim, 1);
+  for (int j = 0; j < ndim; ++j)
+    for (int l = L - 2; l >= 0; --l) w[l * ndim + j] = w[(l + 1) * ndim + j] * f[(l + 1) * ndim + j];
+
+  // forward tables: dest offset per coordinate (decode gather)
+  for (int j = 0; j < ndim; ++j) {
+    std::vector<int64_t> tab(shape[j], 0);
+    for (int64_t x = 0; x < shape[j]; ++x) {
+      int64_t off = 0;
+      for (int l = 0; l < L; ++l) {
+        const int64_t digit = (x / w[l * ndim + j]) % f[l * ndim + j];
+        int64_t inner = 1;  // row-major ravel of the per-dimension digits inside site l
+        for (int jj = j + 1; jj < ndim; ++jj) inner *= f[l * ndim + jj];
+        off += digit * inner * site_stride[l];
+      }
+      tab[x] = off;
+    }
+    plan->host.dim_tab.push_back(tab);
+  }
+
+  // per-site inverse tables: source offset per site index
+  std::vector<std::vector<int64_t>> site_tab(L);
+  for (int l = 0; l < L; ++l) {
+    site_tab[l].assign(site_dim[l], 0);
+    for (int64_t i = 0; i < site_dim[l]; ++i) {
+      int64_t rem = i, off = 0;
+      for (int j = ndim - 1; j >= 0; --j) {
+        const int64_t fj = f[l * ndim + j];
+        off += (rem % fj) * w[l * ndim + j] * src_stride[j];
+        rem /= fj;
+      }
+      site_tab[l][i] = off;
+    }
+  }
+
+  // group consecutive sites, lowest group first (it may be as large as one LDS tile)
+  std::vector<std::pair<int, int>> groups;  // [first_site, last_site] inclusive, low -> high
+  int hi = L - 1;
+  bool lowest = true;
+  while (hi >= 0) {
+    const int64_t cap = lowest ? kTileCap : kGroupCap;
+    int lo = hi;
+    int64_t size = site_dim[hi];
+    while (lo - 1 >= 0 && size * site_dim[lo - 1] <= cap) {
+      --lo;
+      size *= site_dim[lo];
+    }
+    groups.push_back({lo, hi});
+    hi = lo - 1;
+    lowest = false;
+  }
+  NDMPS_REQUIRE((int)groups.size() <= kMaxGroups, "too many site groups (%d)", (int)groups.size());
+  std::reverse(groups.begin(), groups.end());  // now high -> low
+  dp.n_groups = (int)groups.size();
+  std::vector<int64_t> low_table;
+  for (int g = 0; g < dp.n_groups; ++g) {
+    const int a = groups[g].first, b = groups[g].second;
+    int64_t size = 1;
+    for (int l = a; l <= b; ++l) size *= site_dim[l];
+    dp.group_size[g] = size;
+    std::vector<int64_t> tab(size, 0);
+    for (int64_t i = 0; i < size; ++i) {
+      int64_t rem = i, off = 0;
+      for (int l = b; l >= a; --l) {
+        off += site_tab[l][rem % site_dim[l]];
+        rem /= site_dim[l];
+      }
+      tab[i] = off;
+    }
+    plan->host.group_tab.push_back(tab);
+    if (g == dp.n_groups - 1) low_table = tab;
+  }
+
+  // tiled path
+  const int64_t tile = dp.group_size[dp.n_groups - 1];
+  plan->tiled = (tile >= kTileMin && tile <= kTileCap) ? 1 : 0;
+  dp.tile = tile;
+  dp.order = nullptr;
+  dp.src_sorted = nullptr;
+  if (plan->tiled) {
+    std::vector<uint32_t> order(tile);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t x, uint32_t y) { return low_table[x] < low_table[y]; });
+    std::vector<int64_t> sorted(tile);
+    for (int64_t k = 0; k < tile; ++k) sorted[k] = low_table[order[k]];
+    plan->host.order = order;
+    plan->host.src_sorted = sorted;
+  }
+  return NDMPS_OK;
+}
+
+int upload_plan(ndmps_plan* plan) {
+  DevPlan& dp = plan->dev;
+  for (int j = 0; j < dp.ndim; ++j) NDMPS_TRY(upload(plan, plan->host.dim_tab[j], &dp.dim_tab[j]));
+  for (int g = 0; g < dp.n_groups; ++g) NDMPS_TRY(upload(plan, plan->host.group_tab[g], &dp.group_tab[g]));
+  if (plan->tiled) {
+    NDMPS_TRY(upload(plan, plan->host.order, &dp.order));
+    NDMPS_TRY(upload(plan, plan->host.src_sorted, &dp.src_sorted));
+  }
+  return NDMPS_OK;
+}
+
+int grid_for(int64_t work_items, int per_block) {
+  int64_t blocks = ndmps::ceil_div(work_items, per_block);
+  return (int)std::min<int64_t>(std::max<int64_t>(blocks, 1), (int64_t)ndmps::kNumCU * 16);
+}
+
+template <typename T>
+int launch(const ndmps_plan* plan, const void* in, void* out, bool encode, bool force_generic,
+           hipStream_t stream) {
+  const DevPlan& dp = plan->dev;
+  if (plan->tiled && !force_generic) {
+    const int64_t n_tiles = dp.numel / dp.tile;
+    const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ndmps::kNumCU * 8);
+    const size_t lds = (size_t)dp.tile * sizeof(T);
+    if (encode)
+      hipLaunchKernelGGL(encode_tiled_kernel<T>, dim3(grid), dim3(256), lds, stream, dp, (const T*)in,
+                         (T*)out, n_tiles);
+    else
+      hipLaunchKernelGGL(decode_tiled_kernel<T>, dim3(grid), dim3(256), lds, stream, dp, (const T*)in,
+                         (T*)out, n_tiles);
+  } else {
+    const int grid = grid_for(dp.numel, 256);
+    if (encode)
+      hipLaunchKernelGGL(encode_generic_kernel<T>, dim3(grid), dim3(256), 0, stream, dp, (const T*)in,
+                         (T*)out);
+    else
+      hipLaunchKernelGGL(decode_generic_kernel<T>, dim3(grid), dim3(256), 0, stream, dp, (const T*)in,
+                         (T*)out);
+  }
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+int dispatch(const ndmps_plan* plan, const void* in, void* out, int elem_bytes, bool encode,
+             bool force_generic, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(plan != nullptr, "plan is NULL");
+  NDMPS_REQUIRE(in != nullptr && out != nullptr && in != out, "permute needs distinct non-NULL buffers");
+  hipStream_t s = (hipStream_t)stream;
+  switch (elem_bytes) {
+    case 2: return launch<uint16_t>(plan, in, out, encode, force_generic, s);
+    case 4: return launch<uint32_t>(plan, in, out, encode, force_generic, s);
+    case 8: return launch<uint64_t>(plan, in, out, encode, force_generic, s);
+    default:
+      ndmps::set_error("elem_bytes=%d not supported (2, 4 or 8)", elem_bytes);
+      return NDMPS_EINVAL;
+  }
+}
+
+}  // namespace
+
+extern "C" int ndmps_plan_create(ndmps_plan_t** out, int ndim, const int64_t* h_shape, int L,
+                                 const int64_t* h_factor_arr) {
+  NDMPS_REQUIRE(out != nullptr && h_shape != nullptr && h_factor_arr != nullptr, "NULL argument");
+  NDMPS_REQUIRE(ndim >= 1 && ndim <= kMaxDim, "ndim=%d outside [1, %d]", ndim, kMaxDim);
+  NDMPS_REQUIRE(L >= 1 && L <= kMaxSites, "L=%d outside [1, %d]", L, kMaxSites);
+  ndmps_plan* plan = new ndmps_plan();
+  memset(&plan->dev, 0, sizeof(DevPlan));
+  int rc = build_plan(plan, ndim, h_shape, L, h_factor_arr);
+  if (rc == NDMPS_OK) rc = upload_plan(plan);
+  if (rc != NDMPS_OK) {
+    ndmps_plan_destroy(plan);
+    return rc;
+  }
+  *out = plan;
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_plan_destroy(ndmps_plan_t* plan) {
+  if (plan == nullptr) return NDMPS_OK;
+  for (void* p : plan->allocations) (void)hipFree(p);
+  delete plan;
+  return NDMPS_OK;
+}
+
+// Host emulation of the index arithmetic of the kernels above, from the same tables,
+// so the table logic is testable without a GPU.  h_out has numel entries:
+//   mode 0: generic encode  -> source offset read for every site-order position
+//   mode 1: generic decode  -> site-order offset read for every C-order source position
+//   mode 2: tiled encode    -> source offset stored at every site-order position
+//           (h_out[i] = -1 everywhere when the plan is not tiled)
+extern "C" int ndmps_plan_emulate(int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr,
+                                  int mode, int64_t* h_out) {
+  NDMPS_REQUIRE(h_shape && h_factor_arr && h_out, "NULL argument");
+  NDMPS_REQUIRE(ndim >= 1 && ndim <= kMaxDim, "ndim=%d outside [1, %d]", ndim, kMaxDim);
+  NDMPS_REQUIRE(L >= 1 && L <= kMaxSites, "L=%d outside [1, %d]", L, kMaxSites);
+  ndmps_plan plan;
+  memset(&plan.dev, 0, sizeof(DevPlan));
+  NDMPS_TRY(build_plan(&plan, ndim, h_shape, L, h_factor_arr));
+  const DevPlan& p = plan.dev;
+  const HostTables& h = plan.host;
+  if (mode == 0) {
+    for (int64_t o = 0; o < p.numel; ++o) {
+      int64_t rem = o, off = 0;
+      for (int g = p.n_groups - 1; g >= 0; --g) {
+        off += h.group_tab[g][rem % p.group_size[g]];
+        rem /= p.group_size[g];
+      }
+      h_out[o] = off;
+    }
+  } else if (mode == 1) {
+    for (int64_t f = 0; f < p.numel; ++f) {
+      int64_t rem = f, off = 0;
+      for (int j = p.ndim - 1; j >= 0; --j) {
+        off += h.dim_tab[j][rem % p.shape[j]];
+        rem /= p.shape[j];
+      }
+      h_out[f] = off;
+    }
+  } else if (mode == 2) {
+    for (int64_t o = 0; o < p.numel; ++o) h_out[o] = -1;
+    if (plan.tiled) {
+      const int64_t n_tiles = p.numel / p.tile;
+      for (int64_t t = 0; t < n_tiles; ++t) {
+        int64_t rem = t, base = 0;
+        for (int g = p.n_groups - 2; g >= 0; --g) {
+          base += h.group_tab[g][rem % p.group_size[g]];
+          rem /= p.group_size[g];
+        }
+        for (int64_t k = 0; k < p.tile; ++k) h_out[t * p.tile + h.order[k]] = base + h.src_sorted[k];
+      }
+    }
+  } else {
+    ndmps::set_error("mode=%d unknown", mode);
+    return NDMPS_EINVAL;
+  }
+  return plan.tiled;
+}
+
+extern "C" int64_t ndmps_plan_numel(const ndmps_plan_t* plan) { return plan ? plan->dev.numel : -1; }
+extern "C" int ndmps_plan_is_tiled(const ndmps_plan_t* plan) { return plan ? plan->tiled : -1; }
+
+extern "C" int ndmps_encode_permute(const ndmps_plan_t* plan, const void* d_src, void* d_dst,
+                                    int elem_bytes, ndmps_stream_t stream) {
+  return dispatch(plan, d_src, d_dst, elem_bytes, true, false, stream);
+}
+extern "C" int ndmps_decode_permute(const ndmps_plan_t* plan, const void* d_dense, void* d_out,
+                                    int elem_bytes, ndmps_stream_t stream) {
+  return dispatch(plan, d_dense, d_out, elem_bytes, false, false, stream);
+}
+extern "C" int ndmps_encode_permute_generic(const ndmps_plan_t* plan, const void* d_src, void* d_dst,
+                                            int elem_bytes, ndmps_stream_t stream) {
+  return dispatch(plan, d_src, d_dst, elem_bytes, true, true, stream);
+}
+extern "C" int ndmps_decode_permute_generic(const ndmps_plan_t* plan, const void* d_dense, void* d_out,
+                                            int elem_bytes, ndmps_stream_t stream) {
+  return dispatch(plan, d_dense, d_out, elem_bytes, false, true, stream);
+}

@@ -1,0 +1,255 @@
+// Streaming kernels that keep NDMPS state and the storage estimate:
+//   sum of squares (norm=True divides by ||x||_2, core/ndmps.py:60-61),
+//   min/max per core (boundary_list, core/ndmps.py:75, :80-82),
+//   in-place scale, last-axis DCT basis, and the uint8/uint16 core quantisation of
+//   utils/filetools.py:20-39.  All HBM-bound, 16-byte loads where aligned.
+#include <float.h>
+#include <math.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kRedBlocks = 1024;
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// stage 1: per-block partials (fixed grid -> deterministic), stage 2: one block folds them
+__global__ void __launch_bounds__(256)
+sumsq_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const double v = (double)x[i];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256) sum_final_kernel(const double* __restrict__ partial, int count,
+                                                        double* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+minmax_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+  __shared__ float rmin[4], rmax[4];
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float v = x[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if ((threadIdx.x & 63) == 0) {
+    rmin[threadIdx.x >> 6] = lo;
+    rmax[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3]));
+    partial[2 * blockIdx.x + 1] = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+  }
+}
+
+__global__ void __launch_bounds__(256) minmax_final_kernel(const float* __restrict__ partial, int count,
+                                                           float* __restrict__ out) {
+  __shared__ float rmin[256], rmax[256];
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  for (int i = threadIdx.x; i < count; i += 256) {
+    lo = fminf(lo, partial[2 * i]);
+    hi = fmaxf(hi, partial[2 * i + 1]);
+  }
+  rmin[threadIdx.x] = lo;
+  rmax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      rmin[threadIdx.x] = fminf(rmin[threadIdx.x], rmin[threadIdx.x + s]);
+      rmax[threadIdx.x] = fmaxf(rmax[threadIdx.x], rmax[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = rmin[0];
+    out[1] = rmax[0];
+  }
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, int64_t n, double factor) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    x[i] = (float)((double)x[i] * factor);
+}
+
+// forward basis B[j][k] = s_k cos(pi (2j+1) k / (2n)); y = x B is the orthonormal DCT-II
+__global__ void __launch_bounds__(256) dct_basis_kernel(float* __restrict__ basis, int64_t n) {
+  const int64_t total = n * n;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+    const int64_t j = e / n, k = e % n;
+    const int64_t num = ((2 * j + 1) * k) % (4 * n);  // angle = pi * num / (2n), period 4n
+    const double c = cospi((double)num / (double)(2 * n));
+    const double sk = (k == 0) ? sqrt(1.0 / (double)n) : sqrt(2.0 / (double)n);
+    basis[e] = (float)(sk * c);
+  }
+}
+
+template <typename Q>
+__global__ void __launch_bounds__(256)
+quantize_kernel(const float* __restrict__ x, int64_t n, double lo, double span, double qmax,
+                Q* __restrict__ q) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    // (x - min) / max(x - min) * iinfo.max, then a truncating cast (filetools.py:24-26)
+    const double u = ((double)x[i] - lo) / span;
+    q[i] = (Q)(u * qmax);
+  }
+}
+
+template <typename Q>
+__global__ void __launch_bounds__(256)
+dequantize_kernel(const Q* __restrict__ q, int64_t n, double lo, double span, double qmax,
+                  float* __restrict__ x) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    x[i] = (float)(((double)q[i] / qmax) * span + lo);  // filetools.py:38-39
+}
+
+int stream_grid(int64_t n) {
+  return (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(n, 256), 1), (int64_t)ndmps::kNumCU * 8);
+}
+
+}  // namespace
+
+extern "C" int64_t ndmps_reduce_workspace_bytes(void) { return kRedBlocks * 2 * sizeof(double) + 512; }
+
+extern "C" int ndmps_sumsq_f32(const float* d_x, int64_t n, double* h_out, void* d_ws, int64_t ws_bytes,
+                               ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x && h_out && n >= 0, "bad sumsq argument");
+  if (!d_ws || ws_bytes < ndmps_reduce_workspace_bytes()) {
+    ndmps::set_error("reduce workspace too small");
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = (double*)d_ws;
+  double* result = partial + kRedBlocks;
+  const int grid = (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(n, 256 * 8), 1), kRedBlocks);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, s, d_x, n, partial);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, partial, grid, result);
+  NDMPS_LAUNCH_CHECK();
+  NDMPS_CHECK_HIP(hipMemcpyAsync(h_out, result, sizeof(double), hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_minmax_f32(const float* d_x, int64_t n, float* h_min, float* h_max, void* d_ws,
+                                int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x && h_min && h_max && n > 0, "bad minmax argument");
+  if (!d_ws || ws_bytes < ndmps_reduce_workspace_bytes()) {
+    ndmps::set_error("reduce workspace too small");
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)d_ws;
+  float* result = partial + 2 * kRedBlocks;
+  const int grid = (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(n, 256 * 8), 1), kRedBlocks);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(grid), dim3(256), 0, s, d_x, n, partial);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, s, partial, grid, result);
+  NDMPS_LAUNCH_CHECK();
+  float host[2];
+  NDMPS_CHECK_HIP(hipMemcpyAsync(host, result, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  *h_min = host[0];
+  *h_max = host[1];
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_scale_f32(float* d_x, int64_t n, double factor, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x && n >= 0, "bad scale argument");
+  if (n == 0) return NDMPS_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, d_x, n, factor);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_dct_basis_f32(float* d_basis, int64_t n, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_basis && n >= 1 && n <= 16384, "bad DCT length %lld", (long long)n);
+  hipLaunchKernelGGL(dct_basis_kernel, dim3(stream_grid(n * n)), dim3(256), 0, (hipStream_t)stream, d_basis, n);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_dct_last_f32(const float* d_x, float* d_y, int64_t rows, int64_t n,
+                                  const float* d_basis, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x != d_y, "DCT is out of place");
+  return ndmps_sgemm(0, 0, rows, n, n, d_x, n, d_basis, n, d_y, n, stream);
+}
+
+extern "C" int ndmps_idct_last_f32(const float* d_y, float* d_x, int64_t rows, int64_t n,
+                                   const float* d_basis, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x != d_y, "IDCT is out of place");
+  return ndmps_sgemm(0, 1, rows, n, n, d_y, n, d_basis, n, d_x, n, stream);
+}
+
+extern "C" int ndmps_quantize_f32(const float* d_x, int64_t n, float lo, float hi, int bits, void* d_q,
+                                  ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x && d_q && n >= 0, "bad quantize argument");
+  NDMPS_REQUIRE(bits == 8 || bits == 16, "bits=%d not supported (8 or 16)", bits);
+  if (n == 0) return NDMPS_OK;
+  const double span = (double)hi - (double)lo;
+  hipStream_t s = (hipStream_t)stream;
+  if (bits == 8)
+    hipLaunchKernelGGL(quantize_kernel<uint8_t>, dim3(stream_grid(n)), dim3(256), 0, s, d_x, n, (double)lo, span,
+                       255.0, (uint8_t*)d_q);
+  else
+    hipLaunchKernelGGL(quantize_kernel<uint16_t>, dim3(stream_grid(n)), dim3(256), 0, s, d_x, n, (double)lo,
+                       span, 65535.0, (uint16_t*)d_q);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_dequantize_f32(const void* d_q, int64_t n, float lo, float hi, int bits, float* d_x,
+                                    ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x && d_q && n >= 0, "bad dequantize argument");
+  NDMPS_REQUIRE(bits == 8 || bits == 16, "bits=%d not supported (8 or 16)", bits);
+  if (n == 0) return NDMPS_OK;
+  const double span = (double)hi - (double)lo;
+  hipStream_t s = (hipStream_t)stream;
+  if (bits == 8)
+    hipLaunchKernelGGL(dequantize_kernel<uint8_t>, dim3(stream_grid(n)), dim3(256), 0, s, (const uint8_t*)d_q, n,
+                       (double)lo, span, 255.0, d_x);
+  else
+    hipLaunchKernelGGL(dequantize_kernel<uint16_t>, dim3(stream_grid(n)), dim3(256), 0, s, (const uint16_t*)d_q,
+                       n, (double)lo, span, 65535.0, d_x);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}

@@ -1,0 +1,471 @@
+// MPS composites: the SVD sweep, bond truncation, chain contraction and overlap.
+//
+//   ndmps_tt_sweep_f32        <- quimb MatrixProductState.from_dense   (core/ndmps.py:74)
+//   ndmps_compress_bond_f32   <- quimb tensor_compress_bond            (core/ndmps.py:104-106)
+//   ndmps_chain_contract_f32  <- `mps ^ ...`                           (core/ndmps.py:140)
+//   ndmps_overlap_f32         <- `mps @ mps`                           (core/ndmps.py:76,86)
+//
+// SVD strategy (per site, unfolding A of m rows x n cols, fp32 in HBM):
+//   n <= m : G = A^T A in fp64 (exact products), G = V diag(w) V^T by Jacobi; sigma = sqrt(w);
+//            site core = V_k^T (k x n), carry = A V_k (m x k, fp32 MFMA GEMM).
+//   n >  m : G = A A^T in fp64, G = U diag(w) U^T; carry = U_k diag(sigma_k),
+//            core = diag(1/sigma_k) U_k^T A (fp64 GEMM, then fp32).
+// The carried matrix is exact whatever the accuracy of sigma (it is an orthogonal projection
+// of the data); sigma is accurate to ~1e-8 sigma_0 (fp64 Gram of fp32 data).  Singular values
+// below kCutoffFloor * sigma_0 are representation noise of fp32 input and are dropped even
+// when the caller's cutoff is smaller (the reference's 1e-10 presumes fp64 data).
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr double kCutoffFloor = 1e-6;
+
+using ndmps::arena_bytes;
+using ndmps::Arena;
+using ndmps::ceil_div;
+
+inline int grid1d(int64_t n) {
+  return (int)std::min<int64_t>(std::max<int64_t>(ceil_div(n, 256), 1), (int64_t)ndmps::kNumCU * 8);
+}
+
+// ----------------------------------------------------------------------------- small kernels
+__global__ void __launch_bounds__(256) f32_to_f64_kernel(const float* __restrict__ x, int64_t n, double* y) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = (double)x[i];
+}
+
+// core (k x n) fp32 <- first k columns of V (n x n fp64), transposed
+__global__ void __launch_bounds__(256)
+core_from_vectors_kernel(const double* __restrict__ V, int64_t n, int64_t k, float* __restrict__ core) {
+  const int64_t total = k * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / n, c = e % n;
+    core[e] = (float)V[c * n + i];
+  }
+}
+
+// out (rows x k) fp32 <- M (rows x ldm fp64)[:, :k] * scale[col]^power
+__global__ void __launch_bounds__(256)
+scale_cols_to_f32_kernel(const double* __restrict__ M, int64_t rows, int64_t ldm, int64_t k,
+                         const double* __restrict__ sigma, double power, float* __restrict__ out) {
+  const int64_t total = rows * k;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / k, c = e % k;
+    const double sg = sigma[c];
+    out[e] = (float)(sg > 0.0 ? M[r * ldm + c] * pow(sg, power) : 0.0);
+  }
+}
+
+// out (k x n) fp32 <- M (k x n fp64) with row i scaled by sigma[i]^power
+__global__ void __launch_bounds__(256)
+scale_rows_to_f32_kernel(const double* __restrict__ M, int64_t k, int64_t n, const double* __restrict__ sigma,
+                         double power, float* __restrict__ out) {
+  const int64_t total = k * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+  {
+    const double sg = sigma[e / n];
+    out[e] = (float)(sg > 0.0 ? M[e] * pow(sg, power) : 0.0);
+  }
+}
+
+// in-place: M (rows x cols fp64), column c scaled by sqrt(max(w[c], 0))
+__global__ void __launch_bounds__(256)
+scale_cols_sqrt_kernel(double* __restrict__ M, int64_t rows, int64_t cols, const double* __restrict__ w) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    M[e] *= sqrt(fmax(w[e % cols], 0.0));
+}
+
+__global__ void __launch_bounds__(256) sqrt_clamp_kernel(const double* __restrict__ w, int64_t n, double* s) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    s[i] = sqrt(fmax(w[i], 0.0));
+}
+
+// keep s_k > cutoff * s_0 (at least one), at most max_bond
+int64_t kept_rank(const std::vector<double>& sigma, double cutoff, int64_t max_bond) {
+  const int64_t n = (int64_t)sigma.size();
+  const double c = std::max(cutoff, kCutoffFloor);
+  int64_t k = 0;
+  for (int64_t i = 0; i < n; ++i) k += sigma[i] > c * sigma[0];
+  k = std::max<int64_t>(k, 1);
+  if (max_bond > 0) k = std::min(k, max_bond);
+  return std::min(k, n);
+}
+
+// upper bound of ndmps_gram_workspace_bytes(m, n') over every n' <= n (the actual bond may
+// come out smaller than the worst case the layout is sized for): slabs * tiles <=
+// max(1024, tiles(n)), 64 x 64 doubles each.
+int64_t gram_ws_bound(int64_t n) {
+  const int64_t t1 = ceil_div(n, 64);
+  return std::max<int64_t>(1024, t1 * (t1 + 1) / 2) * 4096 * 8 + 256;
+}
+
+// ------------------------------------------------------------------ sweep layout (worst case)
+struct SweepLayout {
+  std::vector<int64_t> max_bonds, core_off, spec_off;
+  int64_t numel = 1;
+  int64_t small_max = 1;      // largest eigenproblem
+  int64_t gram_ws = 0;        // largest Gram workspace
+  int64_t wide_elems = 0;     // largest wide unfolding (m < n), elements
+  int64_t workspace = 0;
+};
+
+int sweep_layout(int L, const int64_t* dims, int64_t max_bond, SweepLayout& out) {
+  NDMPS_REQUIRE(L >= 1 && L <= 64, "L=%d outside [1, 64]", L);
+  out.numel = 1;
+  for (int i = 0; i < L; ++i) {
+    NDMPS_REQUIRE(dims[i] >= 1, "dims[%d]=%lld must be positive", i, (long long)dims[i]);
+    out.numel *= dims[i];
+  }
+  out.max_bonds.assign(L + 1, 1);
+  std::vector<int64_t> left(L + 1, 1), right(L + 1, 1);
+  for (int i = 0; i < L; ++i) left[i + 1] = left[i] * dims[i];
+  for (int i = L - 1; i >= 0; --i) right[i] = right[i + 1] * dims[i];
+  for (int i = 1; i < L; ++i) {
+    int64_t b = std::min(left[i], right[i]);
+    if (max_bond > 0) b = std::min(b, max_bond);
+    out.max_bonds[i] = b;
+  }
+  out.core_off.assign(L + 1, 0);
+  out.spec_off.assign(L + 1, 0);
+  for (int i = 0; i < L; ++i) {
+    out.core_off[i + 1] = out.core_off[i] + ndmps::round_up(out.max_bonds[i] * dims[i] * out.max_bonds[i + 1], 64);
+    const int64_t m = left[i], n = dims[i] * out.max_bonds[i + 1];
+    out.spec_off[i + 1] = out.spec_off[i] + (i == 0 ? 0 : std::min(m, n));
+    if (i >= 1) {
+      const int64_t small = std::min(m, n);
+      out.small_max = std::max(out.small_max, small);
+      if (n <= m) out.gram_ws = std::max(out.gram_ws, gram_ws_bound(n));
+      else out.wide_elems = std::max(out.wide_elems, m * n);
+    }
+  }
+  int64_t used = 0;
+  used = arena_bytes(used, 4, out.numel);                              // second carry buffer
+  used = arena_bytes(used, 8, out.small_max * out.small_max);          // G
+  used = arena_bytes(used, 8, out.small_max * out.small_max);          // V / U
+  used = arena_bytes(used, 8, out.small_max);                          // w
+  used = arena_bytes(used, 8, out.small_max);                          // sigma
+  used = arena_bytes(used, 1, ndmps_syevj_workspace_bytes(out.small_max));
+  used = arena_bytes(used, 1, out.gram_ws);
+  used = arena_bytes(used, 8, out.wide_elems);                         // A64
+  used = arena_bytes(used, 8, out.wide_elems);                         // U_k^T A64
+  out.workspace = ndmps::round_up(used, 256) + 256;
+  return NDMPS_OK;
+}
+
+}  // namespace
+
+extern "C" int ndmps_tt_layout(int L, const int64_t* h_dims, int64_t max_bond, int64_t* h_max_bonds,
+                               int64_t* h_core_offsets, int64_t* h_spec_offsets,
+                               int64_t* h_workspace_bytes) {
+  NDMPS_REQUIRE(h_dims, "NULL dims");
+  SweepLayout lay;
+  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, lay));
+  for (int i = 0; i <= L; ++i) {
+    if (h_max_bonds) h_max_bonds[i] = lay.max_bonds[i];
+    if (h_core_offsets) h_core_offsets[i] = lay.core_off[i];
+    if (h_spec_offsets) h_spec_offsets[i] = lay.spec_off[i];
+  }
+  if (h_workspace_bytes) *h_workspace_bytes = lay.workspace;
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cutoff,
+                                  int64_t max_bond, float* d_cores, const int64_t* h_core_offsets,
+                                  int64_t* h_bonds_out, double* h_spectra, const int64_t* h_spec_offsets,
+                                  void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_dense && h_dims && d_cores && h_core_offsets && h_bonds_out, "NULL sweep argument");
+  NDMPS_REQUIRE(cutoff >= 0.0, "cutoff must be non-negative");
+  SweepLayout lay;
+  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, lay));
+  if (d_ws == nullptr || ws_bytes < lay.workspace) {
+    ndmps::set_error("sweep workspace too small: %lld < %lld", (long long)ws_bytes, (long long)lay.workspace);
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  Arena ar(d_ws, ws_bytes);
+  float* other = ar.take<float>(lay.numel);
+  double* G = ar.take<double>(lay.small_max * lay.small_max);
+  double* V = ar.take<double>(lay.small_max * lay.small_max);
+  double* w = ar.take<double>(lay.small_max);
+  double* sig = ar.take<double>(lay.small_max);
+  const int64_t ev_ws_bytes = ndmps_syevj_workspace_bytes(lay.small_max);
+  char* ev_ws = ar.take<char>(ev_ws_bytes);
+  char* gram_ws = ar.take<char>(lay.gram_ws);
+  double* A64 = ar.take<double>(lay.wide_elems);
+  double* UtA = ar.take<double>(lay.wide_elems);
+  NDMPS_REQUIRE(other && G && V && w && sig && ev_ws && gram_ws && A64 && UtA, "workspace carve failed");
+
+  float* cur = d_dense;
+  float* nxt = other;
+  int64_t cur_elems = lay.numel;
+  int64_t chi_r = 1;
+  h_bonds_out[0] = 1;
+  h_bonds_out[L] = 1;
+  std::vector<double> host_w;
+
+  for (int i = L - 1; i >= 1; --i) {
+    const int64_t n = h_dims[i] * chi_r;
+    const int64_t m = cur_elems / n;
+    const int64_t small = std::min(m, n);
+    float* core = d_cores + h_core_offsets[i];
+    int sweeps = 0;
+    const bool tall = n <= m;
+    if (tall) {
+      NDMPS_TRY(ndmps_gram_f32(cur, m, n, n, G, gram_ws, lay.gram_ws, s));
+    } else {
+      hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(m * n)), dim3(256), 0, s, cur, m * n, A64);
+      NDMPS_LAUNCH_CHECK();
+      NDMPS_TRY(ndmps_dgemm(0, 1, m, m, n, A64, n, A64, n, G, m, s));
+    }
+    NDMPS_TRY(ndmps_syevj_f64(G, small, V, w, ev_ws, ev_ws_bytes, &sweeps, s));
+    host_w.resize(small);
+    NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, small * sizeof(double), hipMemcpyDeviceToHost, s));
+    NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+    for (auto& x : host_w) x = sqrt(std::max(x, 0.0));
+    const int64_t k = kept_rank(host_w, cutoff, max_bond);
+    if (h_spectra && h_spec_offsets)
+      memcpy(h_spectra + h_spec_offsets[i], host_w.data(), small * sizeof(double));
+
+    if (tall) {
+      hipLaunchKernelGGL(core_from_vectors_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, V, n, k, core);
+      NDMPS_LAUNCH_CHECK();
+      NDMPS_TRY(ndmps_sgemm(0, 1, m, k, n, cur, n, core, n, nxt, k, s));
+    } else {
+      hipLaunchKernelGGL(sqrt_clamp_kernel, dim3(grid1d(small)), dim3(256), 0, s, w, small, sig);
+      // carry = U_k diag(sigma_k)
+      hipLaunchKernelGGL(scale_cols_to_f32_kernel, dim3(grid1d(m * k)), dim3(256), 0, s, V, m, m, k, sig, 1.0, nxt);
+      NDMPS_LAUNCH_CHECK();
+      // core = diag(1/sigma_k) U_k^T A
+      NDMPS_TRY(ndmps_dgemm(1, 0, k, n, m, V, m, A64, n, UtA, n, s));
+      hipLaunchKernelGGL(scale_rows_to_f32_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, UtA, k, n, sig, -1.0, core);
+      NDMPS_LAUNCH_CHECK();
+    }
+    std::swap(cur, nxt);
+    cur_elems = m * k;
+    chi_r = k;
+    h_bonds_out[i] = k;
+  }
+  // site 0 carries the norm: (1, d_0, chi_1)
+  NDMPS_CHECK_HIP(hipMemcpyAsync(d_cores + h_core_offsets[0], cur, cur_elems * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  return NDMPS_OK;
+}
+
+// =================================================================== bond truncation
+namespace {
+struct BondLayout {
+  int64_t off[16];
+  int64_t total;
+};
+}  // namespace
+
+extern "C" int64_t ndmps_compress_bond_workspace_bytes(int64_t chi_l, int64_t d1, int64_t chi, int64_t d2,
+                                                       int64_t chi_r) {
+  if (chi_l <= 0 || d1 <= 0 || chi <= 0 || d2 <= 0 || chi_r <= 0) return 0;
+  const int64_t m1 = chi_l * d1, n2 = d2 * chi_r, c2 = chi * chi;
+  int64_t used = 0;
+  used = arena_bytes(used, 8, c2);       // G1
+  used = arena_bytes(used, 8, c2);       // G2 -> destroyed
+  used = arena_bytes(used, 8, c2);       // W2 / Ltilde
+  used = arena_bytes(used, 8, c2);       // tmp = G1 Ltilde
+  used = arena_bytes(used, 8, c2);       // H
+  used = arena_bytes(used, 8, c2);       // V
+  used = arena_bytes(used, 8, c2);       // P1 = Ltilde V
+  used = arena_bytes(used, 8, c2);       // P2 = tmp V
+  used = arena_bytes(used, 8, chi);      // w2
+  used = arena_bytes(used, 8, chi);      // wh
+  used = arena_bytes(used, 8, chi);      // sigma
+  used = arena_bytes(used, 4, c2);       // A1 fp32
+  used = arena_bytes(used, 4, c2);       // B2 fp32
+  used = arena_bytes(used, 8, chi * n2); // t2 in fp64
+  used = arena_bytes(used, 1, ndmps_syevj_workspace_bytes(chi));
+  used = arena_bytes(used, 1, ndmps_gram_workspace_bytes(m1, chi));
+  return ndmps::round_up(used, 256) + 256;
+}
+
+// Truncated SVD of the two-site product P = T1 T2 through the bond, without forming P or
+// Q factors: with G1 = T1^T T1, G2 = T2 T2^T = W D W^T, Lt = W D^(1/2) and H = Lt^T G1 Lt
+// = V diag(s^2) V^T (the s are the singular values of P), the absorb-"both" cores are
+//   T1' = T1 (Lt V_k) s_k^(-1/2),   T2' = s_k^(-3/2) (G1 Lt V_k)^T T2 .
+extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int64_t chi_l, int64_t d1,
+                                       int64_t chi, int64_t d2, int64_t chi_r, double cutoff,
+                                       int64_t max_bond, float* d_new1, float* d_new2, int64_t* h_new_chi,
+                                       double* h_s, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_t1 && d_t2 && d_new1 && d_new2 && h_new_chi, "NULL compress_bond argument");
+  NDMPS_REQUIRE(chi_l > 0 && d1 > 0 && chi > 0 && d2 > 0 && chi_r > 0, "bad core shape");
+  NDMPS_REQUIRE(cutoff >= 0.0, "cutoff must be non-negative");
+  const int64_t need = ndmps_compress_bond_workspace_bytes(chi_l, d1, chi, d2, chi_r);
+  if (!d_ws || ws_bytes < need) {
+    ndmps::set_error("compress_bond workspace too small: %lld < %lld", (long long)ws_bytes, (long long)need);
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t m1 = chi_l * d1, n2 = d2 * chi_r, c2 = chi * chi;
+  Arena ar(d_ws, ws_bytes);
+  double* G1 = ar.take<double>(c2);
+  double* G2 = ar.take<double>(c2);
+  double* Lt = ar.take<double>(c2);
+  double* tmp = ar.take<double>(c2);
+  double* H = ar.take<double>(c2);
+  double* V = ar.take<double>(c2);
+  double* P1 = ar.take<double>(c2);
+  double* P2 = ar.take<double>(c2);
+  double* w2 = ar.take<double>(chi);
+  double* wh = ar.take<double>(chi);
+  double* sig = ar.take<double>(chi);
+  float* A1 = ar.take<float>(c2);
+  float* B2 = ar.take<float>(c2);
+  double* t2d = ar.take<double>(chi * n2);
+  const int64_t ev_bytes = ndmps_syevj_workspace_bytes(chi);
+  char* ev_ws = ar.take<char>(ev_bytes);
+  const int64_t gram_bytes = ndmps_gram_workspace_bytes(m1, chi);
+  char* gram_ws = ar.take<char>(gram_bytes);
+  NDMPS_REQUIRE(G1 && G2 && Lt && tmp && H && V && P1 && P2 && w2 && wh && sig && A1 && B2 && t2d && ev_ws &&
+                    gram_ws,
+                "workspace carve failed");
+
+  int sweeps = 0;
+  NDMPS_TRY(ndmps_gram_f32(d_t1, m1, chi, chi, G1, gram_ws, gram_bytes, s));
+  hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(chi * n2)), dim3(256), 0, s, d_t2, chi * n2, t2d);
+  NDMPS_LAUNCH_CHECK();
+  NDMPS_TRY(ndmps_dgemm(0, 1, chi, chi, n2, t2d, n2, t2d, n2, G2, chi, s));
+  NDMPS_TRY(ndmps_syevj_f64(G2, chi, Lt, w2, ev_ws, ev_bytes, &sweeps, s));
+  hipLaunchKernelGGL(scale_cols_sqrt_kernel, dim3(grid1d(c2)), dim3(256), 0, s, Lt, chi, chi, w2);
+  NDMPS_LAUNCH_CHECK();
+  NDMPS_TRY(ndmps_dgemm(0, 0, chi, chi, chi, G1, chi, Lt, chi, tmp, chi, s));
+  NDMPS_TRY(ndmps_dgemm(1, 0, chi, chi, chi, Lt, chi, tmp, chi, H, chi, s));
+  NDMPS_TRY(ndmps_syevj_f64(H, chi, V, wh, ev_ws, ev_bytes, &sweeps, s));  // symmetrises H on entry
+
+  std::vector<double> sv(chi);
+  NDMPS_CHECK_HIP(hipMemcpyAsync(sv.data(), wh, chi * sizeof(double), hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  for (auto& x : sv) x = sqrt(std::max(x, 0.0));  // eigenvalues of H are s^2
+  const int64_t k = kept_rank(sv, cutoff, max_bond);
+  if (h_s) memcpy(h_s, sv.data(), chi * sizeof(double));
+  *h_new_chi = k;
+
+  hipLaunchKernelGGL(sqrt_clamp_kernel, dim3(grid1d(chi)), dim3(256), 0, s, wh, chi, sig);
+  NDMPS_LAUNCH_CHECK();
+  NDMPS_TRY(ndmps_dgemm(0, 0, chi, k, chi, Lt, chi, V, chi, P1, k, s));
+  NDMPS_TRY(ndmps_dgemm(0, 0, chi, k, chi, tmp, chi, V, chi, P2, k, s));
+  hipLaunchKernelGGL(scale_cols_to_f32_kernel, dim3(grid1d(chi * k)), dim3(256), 0, s, P1, chi, k, k, sig, -0.5, A1);
+  hipLaunchKernelGGL(scale_cols_to_f32_kernel, dim3(grid1d(chi * k)), dim3(256), 0, s, P2, chi, k, k, sig, -1.5, B2);
+  NDMPS_LAUNCH_CHECK();
+  NDMPS_TRY(ndmps_sgemm(0, 0, m1, k, chi, d_t1, chi, A1, k, d_new1, k, s));      // (chi_l d1, k)
+  NDMPS_TRY(ndmps_sgemm(1, 0, k, n2, chi, B2, k, d_t2, n2, d_new2, n2, s));      // (k, d2 chi_r)
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  return NDMPS_OK;
+}
+
+// =================================================================== chain contraction
+extern "C" int64_t ndmps_chain_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds) {
+  if (L < 1 || !h_dims || !h_bonds) return 0;
+  int64_t rows = 1, biggest = 1;
+  for (int i = 0; i < L; ++i) {
+    rows *= h_dims[i];
+    biggest = std::max(biggest, rows * h_bonds[i + 1]);
+  }
+  return biggest * (int64_t)sizeof(float) + 512;
+}
+
+extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                                        const float* const* h_cores, float* d_dense, void* d_ws,
+                                        int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(L >= 1 && h_dims && h_bonds && h_cores && d_dense, "bad chain argument");
+  NDMPS_REQUIRE(h_bonds[0] == 1 && h_bonds[L] == 1, "open boundary bonds must be 1");
+  const int64_t need = ndmps_chain_workspace_bytes(L, h_dims, h_bonds);
+  if (!d_ws || ws_bytes < need) {
+    ndmps::set_error("chain workspace too small: %lld < %lld", (long long)ws_bytes, (long long)need);
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* bufs[2] = {d_dense, (float*)d_ws};
+  // L-1 GEMMs; arrange the ping-pong so the last one lands in d_dense
+  int dst = (L - 1) % 2 == 0 ? 0 : 1;  // buffer that receives the copy of core 0
+  int64_t rows = h_dims[0];
+  NDMPS_CHECK_HIP(hipMemcpyAsync(bufs[dst], h_cores[0], rows * h_bonds[1] * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+  for (int i = 1; i < L; ++i) {
+    const int64_t chi = h_bonds[i], cols = h_dims[i] * h_bonds[i + 1];
+    NDMPS_TRY(ndmps_sgemm(0, 0, rows, cols, chi, bufs[dst], chi, h_cores[i], cols, bufs[dst ^ 1], cols, s));
+    dst ^= 1;
+    rows *= h_dims[i];
+  }
+  NDMPS_REQUIRE(dst == 0, "internal: chain result landed in the wrong buffer");
+  return NDMPS_OK;
+}
+
+// =================================================================== overlap
+extern "C" int64_t ndmps_overlap_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
+                                                 const int64_t* h_bonds_b) {
+  if (L < 1 || !h_dims || !h_bonds_a || !h_bonds_b) return 0;
+  int64_t emax = 1, amax = 1, bmax = 1, xmax = 1;
+  for (int i = 0; i < L; ++i) {
+    emax = std::max(emax, h_bonds_a[i + 1] * h_bonds_b[i + 1]);
+    amax = std::max(amax, h_bonds_a[i] * h_dims[i] * h_bonds_a[i + 1]);
+    bmax = std::max(bmax, h_bonds_b[i] * h_dims[i] * h_bonds_b[i + 1]);
+    xmax = std::max(xmax, h_bonds_b[i] * h_dims[i] * h_bonds_a[i + 1]);
+  }
+  int64_t used = 0;
+  used = arena_bytes(used, 8, emax);
+  used = arena_bytes(used, 8, emax);
+  used = arena_bytes(used, 8, amax);
+  used = arena_bytes(used, 8, bmax);
+  used = arena_bytes(used, 8, xmax);
+  return ndmps::round_up(used, 256) + 256;
+}
+
+extern "C" int ndmps_overlap_f32(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
+                                 const float* const* h_cores_a, const int64_t* h_bonds_b,
+                                 const float* const* h_cores_b, double* h_out, void* d_ws,
+                                 int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(L >= 1 && h_dims && h_bonds_a && h_bonds_b && h_cores_a && h_cores_b && h_out,
+                "bad overlap argument");
+  const int64_t need = ndmps_overlap_workspace_bytes(L, h_dims, h_bonds_a, h_bonds_b);
+  if (!d_ws || ws_bytes < need) {
+    ndmps::set_error("overlap workspace too small: %lld < %lld", (long long)ws_bytes, (long long)need);
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int64_t emax = 1, amax = 1, bmax = 1, xmax = 1;
+  for (int i = 0; i < L; ++i) {
+    emax = std::max(emax, h_bonds_a[i + 1] * h_bonds_b[i + 1]);
+    amax = std::max(amax, h_bonds_a[i] * h_dims[i] * h_bonds_a[i + 1]);
+    bmax = std::max(bmax, h_bonds_b[i] * h_dims[i] * h_bonds_b[i + 1]);
+    xmax = std::max(xmax, h_bonds_b[i] * h_dims[i] * h_bonds_a[i + 1]);
+  }
+  Arena ar(d_ws, ws_bytes);
+  double* E[2] = {ar.take<double>(emax), ar.take<double>(emax)};
+  double* A = ar.take<double>(amax);
+  double* B = ar.take<double>(bmax);
+  double* X = ar.take<double>(xmax);
+  NDMPS_REQUIRE(E[0] && E[1] && A && B && X, "workspace carve failed");
+
+  const double one = 1.0;
+  NDMPS_CHECK_HIP(hipMemcpyAsync(E[0], &one, sizeof(double), hipMemcpyHostToDevice, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));  // `one` lives on this stack frame
+  int cur = 0;
+  for (int i = 0; i < L; ++i) {
+    const int64_t ca = h_bonds_a[i], ca2 = h_bonds_a[i + 1];
+    const int64_t cb = h_bonds_b[i], cb2 = h_bonds_b[i + 1];
+    const int64_t d = h_dims[i];
+    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(ca * d * ca2)), dim3(256), 0, s, h_cores_a[i], ca * d * ca2, A);
+    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(cb * d * cb2)), dim3(256), 0, s, h_cores_b[i], cb * d * cb2, B);
+    NDMPS_LAUNCH_CHECK();
+    // X (cb, d ca2) = E^T (cb, ca) A (ca, d ca2)
+    NDMPS_TRY(ndmps_dgemm(1, 0, cb, d * ca2, ca, E[cur], cb, A, d * ca2, X, d * ca2, s));
+    // E' (ca2, cb2) = X'^T B' with X' = (cb d, ca2), B' = (cb d, cb2)
+    NDMPS_TRY(ndmps_dgemm(1, 0, ca2, cb2, cb * d, X, ca2, B, cb2, E[cur ^ 1], cb2, s));
+    cur ^= 1;
+  }
+  NDMPS_CHECK_HIP(hipMemcpyAsync(h_out, E[cur], sizeof(double), hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  return NDMPS_OK;
+}

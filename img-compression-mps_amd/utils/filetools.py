@@ -1,0 +1,74 @@
+"""Quantise helpers of the storage estimate, device side.
+
+Mirrors src/imgcompressionmps/utils/filetools.py:7-39 (``get_num_bits``,
+``scale_to_dtype``, ``scale_back``) for fp32 cores resident in HBM; the arithmetic runs in
+csrc/reduce.hip (ndmps_quantize_f32 / ndmps_dequantize_f32 / ndmps_minmax_f32) with the
+reference's truncating cast and min-max scaling.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+
+
+def get_num_bits(dtype) -> int:
+    dtype = np.dtype(dtype)
+    if np.issubdtype(dtype, np.integer):
+        return np.iinfo(dtype).bits
+    if np.issubdtype(dtype, np.floating):
+        return np.finfo(dtype).bits
+    raise ValueError(f"Unsupported dtype {dtype!r}")
+
+
+def _bits(dtype) -> int:
+    dtype = np.dtype(dtype)
+    if dtype == np.uint8:
+        return 8
+    if dtype == np.uint16:
+        return 16
+    raise ValueError(f"Unsupported dtype {dtype!r}: the device path quantises to uint8 or uint16")
+
+
+def minmax(t):
+    """(min, max) of a device fp32 tensor as Python floats."""
+    import torch
+
+    lib = _lib.load()
+    ws = torch.empty(lib.ndmps_reduce_workspace_bytes(), dtype=torch.uint8, device=t.device)
+    lo, hi = C.c_float(), C.c_float()
+    t = t.contiguous()
+    _lib.check(lib.ndmps_minmax_f32(t.data_ptr(), t.numel(), C.byref(lo), C.byref(hi), ws.data_ptr(),
+                                    ws.numel(), _lib.stream_ptr()))
+    return float(lo.value), float(hi.value)
+
+
+def scale_to_dtype(t, dtype=np.uint8):
+    """Device tensor -> unsigned-int device tensor, (x - min) / max(x - min) * iinfo.max, truncated."""
+    import torch
+
+    bits = _bits(dtype)
+    lib = _lib.load()
+    t = t.contiguous()
+    lo, hi = minmax(t)
+    # torch has no uint16 arithmetic, but int16 storage has the same bytes
+    q = torch.empty(t.shape, dtype=torch.uint8 if bits == 8 else torch.int16, device=t.device)
+    _lib.check(lib.ndmps_quantize_f32(t.data_ptr(), t.numel(), lo, hi, bits, q.data_ptr(), _lib.stream_ptr()))
+    return q
+
+
+def scale_back(q, arr_min, arr_max, dtype=np.uint8):
+    import torch
+
+    bits = _bits(dtype)
+    lib = _lib.load()
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    _lib.check(lib.ndmps_dequantize_f32(q.data_ptr(), q.numel(), float(arr_min), float(arr_max), bits,
+                                        out.data_ptr(), _lib.stream_ptr()))
+    return out
+
+
+def to_numpy_uint(q, dtype):
+    """Host copy of a quantised device tensor with the requested unsigned dtype."""
+    arr = q.cpu().numpy()
+    return arr.view(np.dtype(dtype)) if arr.dtype != np.dtype(dtype) else arr

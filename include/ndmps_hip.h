@@ -1,0 +1,188 @@
+/*
+ * ndmps_hip.h -- C ABI of libndmps_hip.so, the MI355X (gfx950) implementation of the
+ * NDMPS encode -> truncate -> reconstruct hot path of Alandroid/img-compression-mps.
+ *
+ * The reference has no FFI: its hot path is Python calling quimb / NumPy / SciPy
+ * (SURVEY.md 8b).  Each entry point below therefore names the reference call it
+ * replaces (file:line relative to /root/reference/src/imgcompressionmps/).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory (HBM) owned by the caller; h_* is host.
+ *   - all matrices are row-major; cores are (chi_i, d_i, chi_{i+1}) row-major.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).
+ *   - every function returns 0 on success, a negative NDMPS_E* code otherwise;
+ *     ndmps_last_error() returns a thread-local message for the last failure.
+ *   - no function allocates device memory except ndmps_plan_create(); workspaces are
+ *     caller-provided and sized by the *_layout / *_workspace_bytes queries.
+ *   - functions that return data-dependent bond sizes synchronise `stream` internally.
+ */
+#ifndef NDMPS_HIP_H
+#define NDMPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDMPS_OK 0
+#define NDMPS_EINVAL (-1)   /* bad argument (maps to ValueError) */
+#define NDMPS_EHIP (-2)     /* HIP runtime failure (maps to RuntimeError) */
+#define NDMPS_ENOCONV (-3)  /* eigen-solver did not converge */
+#define NDMPS_EWORKSPACE (-4) /* workspace too small */
+
+typedef void* ndmps_stream_t;
+typedef struct ndmps_plan ndmps_plan_t;
+
+int ndmps_version(void);
+const char* ndmps_last_error(void);
+/* number of HIP devices visible, or a negative code; never initialises a context */
+int ndmps_device_count(void);
+
+/* ---------------------------------------------------------------------------------
+ * Index permutation ("reshape stage").
+ * Replaces: utils/core.py:6-35,129-168 (gen_encoding_map, never materialised here),
+ *           core/ndmps.py:66-71 (scatter  contracted[enc] = tensor.flatten()) and
+ *           core/ndmps.py:144-148 (gather recovered = dense[enc]).
+ * factor_arr is the (L, ndim) int64 array of utils/core.py:79-126 (get_factorlist).
+ * --------------------------------------------------------------------------------- */
+int ndmps_plan_create(ndmps_plan_t** out, int ndim, const int64_t* h_shape, int L,
+                      const int64_t* h_factor_arr);
+int ndmps_plan_destroy(ndmps_plan_t* plan);
+int64_t ndmps_plan_numel(const ndmps_plan_t* plan);
+/* 1 if the LDS-tiled kernels are used for this plan, 0 for the generic gather */
+int ndmps_plan_is_tiled(const ndmps_plan_t* plan);
+/* Host-only emulation of the kernels' index arithmetic from the plan's tables (no GPU
+ * needed; used by the CPU tests).  h_out[numel]: mode 0 = source offset read per site-order
+ * position (generic encode), 1 = site-order offset read per C-order position (generic
+ * decode), 2 = source offset stored per site-order position by the tiled kernels (-1 when
+ * the plan is not tiled).  Returns 1/0 (tiled or not) or a negative error code. */
+int ndmps_plan_emulate(int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr,
+                       int mode, int64_t* h_out);
+/* dst (C-order over site dims d_0..d_{L-1}) <- src (C-order over shape); bit-exact */
+int ndmps_encode_permute(const ndmps_plan_t* plan, const void* d_src, void* d_dst,
+                         int elem_bytes, ndmps_stream_t stream);
+/* out (C-order over shape) <- dense (C-order over site dims); bit-exact */
+int ndmps_decode_permute(const ndmps_plan_t* plan, const void* d_dense, void* d_out,
+                         int elem_bytes, ndmps_stream_t stream);
+/* force the generic gather kernels (testing / A-B timing) */
+int ndmps_encode_permute_generic(const ndmps_plan_t* plan, const void* d_src, void* d_dst,
+                                 int elem_bytes, ndmps_stream_t stream);
+int ndmps_decode_permute_generic(const ndmps_plan_t* plan, const void* d_dense, void* d_out,
+                                 int elem_bytes, ndmps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Last-axis orthonormal DCT-II / DCT-III.
+ * Replaces: scipy.fftpack.dct / idct at core/ndmps.py:62-63 and :152-153.
+ * d_x, d_y: (rows, n) row-major fp32; d_basis: (n, n) fp32 scratch filled by
+ * ndmps_dct_basis_f32 once per n (forward basis B[j][k] = s_k cos(pi (2j+1) k / 2n)).
+ * --------------------------------------------------------------------------------- */
+int ndmps_dct_basis_f32(float* d_basis, int64_t n, ndmps_stream_t stream);
+int ndmps_dct_last_f32(const float* d_x, float* d_y, int64_t rows, int64_t n,
+                       const float* d_basis, ndmps_stream_t stream);
+int ndmps_idct_last_f32(const float* d_y, float* d_x, int64_t rows, int64_t n,
+                        const float* d_basis, ndmps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Reductions that keep NDMPS state (core/ndmps.py:60-61 norm, :75,:80-82 boundary_list).
+ * h_out / d_out as named; *_f32 read fp32 and accumulate in fp64.
+ * --------------------------------------------------------------------------------- */
+int ndmps_sumsq_f32(const float* d_x, int64_t n, double* h_out, void* d_ws, int64_t ws_bytes,
+                    ndmps_stream_t stream);
+int ndmps_minmax_f32(const float* d_x, int64_t n, float* h_min, float* h_max, void* d_ws,
+                     int64_t ws_bytes, ndmps_stream_t stream);
+int ndmps_scale_f32(float* d_x, int64_t n, double factor, ndmps_stream_t stream);
+int64_t ndmps_reduce_workspace_bytes(void);
+
+/* ---------------------------------------------------------------------------------
+ * Dense building blocks (exported for tests and for INTEGRATION.md users).
+ * --------------------------------------------------------------------------------- */
+/* C(m,n) = op(A)(m,k) op(B)(k,n), fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate */
+int ndmps_sgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const float* d_A,
+                int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+                ndmps_stream_t stream);
+/* same in fp64 (v_mfma_f64_16x16x4_f64) */
+int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const double* d_A,
+                int64_t lda, const double* d_B, int64_t ldb, double* d_C, int64_t ldc,
+                ndmps_stream_t stream);
+/* G(n,n) fp64 = A^T A for A (m,n) fp32 row-major; products exact, fp64 accumulation */
+int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n);
+int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
+                   void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+/* symmetric eigen-decomposition (two-sided parallel Jacobi, fp64): G = V diag(w) V^T,
+ * w descending, eigenvectors in the COLUMNS of V, each with its largest-magnitude
+ * component positive.  d_G is destroyed.  Synchronises the stream. */
+int64_t ndmps_syevj_workspace_bytes(int64_t n);
+int ndmps_syevj_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
+                    int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * MPS sweep: replaces quimb MatrixProductState.from_dense (core/ndmps.py:74).
+ * Right->left, per site: unfold (prod_{j<i} d_j) x (d_i chi_{i+1}) -> SVD (Gram + Jacobi,
+ * fp64 small-side) -> keep s_k > cutoff*s_0, at most max_bond (<=0: unlimited) -> V^T is
+ * site i, U S is carried left.  Cores are written fp32 at d_cores + core_offsets[i].
+ *
+ * ndmps_tt_layout fills (all host arrays of L+1 entries):
+ *   h_max_bonds[i]   upper bound of chi_i (chi_0 = chi_L = 1)
+ *   h_core_offsets[i] element offset of core i in the arena; [L] = arena elements
+ *   h_spec_offsets[i] offset of bond i's singular values in h_spectra; [L] = total
+ *   *h_workspace_bytes device workspace needed by ndmps_tt_sweep_f32
+ * --------------------------------------------------------------------------------- */
+int ndmps_tt_layout(int L, const int64_t* h_dims, int64_t max_bond, int64_t* h_max_bonds,
+                    int64_t* h_core_offsets, int64_t* h_spec_offsets,
+                    int64_t* h_workspace_bytes);
+/* d_dense: N fp32 in site order (output of ndmps_encode_permute); it is overwritten.
+ * h_bonds_out: L+1 actual bonds; h_spectra (may be NULL): singular values per bond. */
+int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cutoff,
+                       int64_t max_bond, float* d_cores, const int64_t* h_core_offsets,
+                       int64_t* h_bonds_out, double* h_spectra, const int64_t* h_spec_offsets,
+                       void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Bond truncation: replaces quimb tensor_compress_bond(t1, t2, cutoff, cutoff_mode="rel")
+ * (core/ndmps.py:104-106; reduced=True, absorb="both").  t1 (chi_l, d1, chi),
+ * t2 (chi, d2, chi_r) fp32.  New cores are written to d_new1 / d_new2 (sized for chi),
+ * *h_new_chi receives the kept bond; h_s (may be NULL) receives chi singular values.
+ * --------------------------------------------------------------------------------- */
+int64_t ndmps_compress_bond_workspace_bytes(int64_t chi_l, int64_t d1, int64_t chi, int64_t d2,
+                                            int64_t chi_r);
+int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int64_t chi_l, int64_t d1,
+                            int64_t chi, int64_t d2, int64_t chi_r, double cutoff,
+                            int64_t max_bond, float* d_new1, float* d_new2, int64_t* h_new_chi,
+                            double* h_s, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Chain contraction: replaces `mps ^ ...` (core/ndmps.py:140), cumulative left->right.
+ * h_cores: host array of L device pointers; h_bonds: L+1 bonds.  d_dense receives the
+ * (d_0..d_{L-1}) tensor, N fp32.
+ * --------------------------------------------------------------------------------- */
+int64_t ndmps_chain_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds);
+int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                             const float* const* h_cores, float* d_dense, void* d_ws,
+                             int64_t ws_bytes, ndmps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Overlap: replaces `mps @ mps` (core/ndmps.py:76,86; utils/metrics.py:160), real data,
+ * no conjugation, fp64 transfer matrices.  Synchronises the stream.
+ * --------------------------------------------------------------------------------- */
+int64_t ndmps_overlap_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
+                                      const int64_t* h_bonds_b);
+int ndmps_overlap_f32(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
+                      const float* const* h_cores_a, const int64_t* h_bonds_b,
+                      const float* const* h_cores_b, double* h_out, void* d_ws,
+                      int64_t ws_bytes, ndmps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Core quantisation: utils/filetools.py:20-39 scale_to_dtype/scale_back
+ * with the reference's truncating cast.  bits = 8 or 16.
+ * --------------------------------------------------------------------------------- */
+int ndmps_quantize_f32(const float* d_x, int64_t n, float lo, float hi, int bits, void* d_q,
+                       ndmps_stream_t stream);
+int ndmps_dequantize_f32(const void* d_q, int64_t n, float lo, float hi, int bits, float* d_x,
+                         ndmps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDMPS_HIP_H */

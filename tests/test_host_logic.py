@@ -1,0 +1,187 @@
+"""CPU-side tests of the product: host index-map logic, the C ABI surface and the plan
+tables (through ndmps_plan_emulate, which runs the kernels' index arithmetic on the host).
+No compute entry point is called here -- there is no GPU in the build container."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import imgcompressionmps_amd as pkg
+from imgcompressionmps_amd import _lib
+from imgcompressionmps_amd.utils import core as hc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _small(golden_dir):
+    return np.load(os.path.join(golden_dir, "index_map_small.npz"))
+
+
+def test_host_factorlist_and_map_match_reference_fixtures(golden_dir):
+    g = _small(golden_dir)
+    for key in sorted({k.split("/")[0] for k in g.files}):
+        shape = tuple(int(s) for s in key.split("x"))
+        f, p = hc.get_factorlist(shape)
+        assert np.array_equal(f, g[key + "/factor_arr"]), key
+        assert np.array_equal(p, g[key + "/prod"]), key
+        q, enc = hc.gen_encoding_map(shape)
+        assert np.array_equal(q, g[key + "/qubit_size"]) and np.array_equal(enc, g[key + "/enc_map"]), key
+        assert np.array_equal(hc.site_dims(shape), g[key + "/qubit_size"])
+
+
+def test_host_known_answers_from_reference_tests():
+    # /root/reference/tests/utils/test_core.py:75-88,111-122
+    f, p = hc.get_factorlist((256, 128))
+    assert np.array_equal(f, [[2, 2]] * 6 + [[4, 2]])
+    assert p[1:].tolist() == [[128, 64], [64, 32], [32, 16], [16, 8], [8, 4], [4, 2], [1, 1]]
+    f, p = hc.get_factorlist((30, 40, 50))
+    assert np.array_equal(f, [[2, 5, 2], [3, 4, 5], [5, 2, 5]])
+    assert p[1:].tolist() == [[15, 8, 25], [5, 2, 5], [1, 1, 1]]
+    assert hc.balance_factors([2] * 10, 2) == [16, 64]  # value produced by the reference itself
+    assert hc.balance_factors([], 0) == []
+
+
+def test_host_errors_match_reference():
+    for bad in [(), (0, 4), ("a", "b"), (3, -1)]:
+        with pytest.raises(ValueError):
+            hc.get_factorlist(bad)
+        with pytest.raises(ValueError):
+            hc.gen_encoding_map(bad)
+    with pytest.raises(ValueError):
+        hc.balance_factors([2, 3], -1)
+    with pytest.raises(ValueError):
+        hc.balance_factors([2, 3], 0)
+    with pytest.raises(ValueError):
+        hc.balance_factors([2], 2)
+    with pytest.raises(ValueError):
+        hc.hierarchical_block_indexing(np.indices((4, 4)), np.array([[1, 1]]))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "ndmps_hip.h")).read()
+    declared = set(re.findall(r"\b(ndmps_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ndmps_plan", "ndmps_plan_t", "ndmps_stream_t"}
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ndmps_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == declared
+    assert lib.ndmps_version() >= 100
+
+
+def _emulate(shape, mode):
+    lib = _lib.load()
+    f, _ = hc.get_factorlist(shape)
+    f = np.ascontiguousarray(f, dtype=np.int64)
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.int64)
+    rc = lib.ndmps_plan_emulate(len(shape), _lib.i64_array(shape), f.shape[0],
+                                f.ctypes.data_as(_lib.p_i64), mode, out.ctypes.data_as(_lib.p_i64))
+    assert rc >= 0, lib.ndmps_last_error()
+    return rc, out
+
+
+def test_plan_tables_reproduce_reference_permutation_small(golden_dir):
+    g = _small(golden_dir)
+    for key in sorted({k.split("/")[0] for k in g.files}):
+        shape = tuple(int(s) for s in key.split("x"))
+        flat_dest = g[key + "/flat_dest"].astype(np.int64)  # dest offset per C-order source voxel
+        inverse = np.empty_like(flat_dest)
+        inverse[flat_dest] = np.arange(flat_dest.size)
+        _, enc_src = _emulate(shape, 0)
+        assert np.array_equal(enc_src, inverse), key
+        _, dec_off = _emulate(shape, 1)
+        assert np.array_equal(dec_off, flat_dest), key
+        tiled, til_src = _emulate(shape, 2)
+        if tiled:
+            assert np.array_equal(til_src, inverse), key
+        else:
+            assert np.all(til_src == -1)
+
+
+def test_plan_tables_reproduce_reference_permutation_large(golden_dir):
+    with open(os.path.join(golden_dir, "index_map_hashes.json")) as fh:
+        hashes = json.load(fh)
+    n_tiled = 0
+    for key, rec in hashes.items():
+        shape = tuple(int(s) for s in key.split("x"))
+        _, dec_off = _emulate(shape, 1)
+        assert hashlib.sha256(dec_off.tobytes()).hexdigest() == rec["flat_dest_sha256"], key
+        inverse = np.empty_like(dec_off)
+        inverse[dec_off] = np.arange(dec_off.size)
+        _, enc_src = _emulate(shape, 0)
+        assert np.array_equal(enc_src, inverse), key
+        tiled, til_src = _emulate(shape, 2)
+        n_tiled += tiled
+        if tiled:
+            assert np.array_equal(til_src, inverse), key
+    assert n_tiled >= 3  # 128^3, 64^3 and 512x680 take the LDS-tiled path
+
+
+def test_plan_rejects_bad_factor_arrays():
+    lib = _lib.load()
+    out = np.empty(8, dtype=np.int64)
+    bad = np.array([[2, 2], [2, 3]], dtype=np.int64)  # multiplies to (4, 6), shape says (4, 4)
+    rc = lib.ndmps_plan_emulate(2, _lib.i64_array((4, 4)), 2, bad.ctypes.data_as(_lib.p_i64), 0,
+                                out.ctypes.data_as(_lib.p_i64))
+    assert rc == _lib.EINVAL
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+
+
+def test_tt_layout_matches_survey_table():
+    lib = _lib.load()
+
+    def layout(dims, max_bond):
+        L = len(dims)
+        mb, co, so = ((C.c_int64 * (L + 1))() for _ in range(3))
+        ws = C.c_int64()
+        _lib.check(lib.ndmps_tt_layout(L, _lib.i64_array(dims), max_bond, mb, co, so, C.byref(ws)))
+        return list(mb), list(co), list(so), ws.value
+
+    mb, co, so, ws = layout([8] * 8, 64)  # 256^3, chi = 64
+    assert mb == [1, 8, 64, 64, 64, 64, 64, 8, 1]
+    assert co[-1] >= 139392 and ws > 4 * 8 ** 8
+    mb, *_ = layout([8] * 8, 0)
+    assert mb == [1, 8, 64, 512, 4096, 512, 64, 8, 1]
+    mb, *_ = layout([64, 32, 16, 16, 16, 32], 128)  # config 5
+    assert mb == [1, 64, 128, 128, 128, 32, 1]
+    mb, co, so, ws = layout([84], 0)  # single site, no bonds
+    assert mb == [1, 1] and so[-1] == 0
+
+
+def test_workspace_queries_and_argument_checks_need_no_gpu():
+    lib = _lib.load()
+    assert lib.ndmps_gram_workspace_bytes(32768, 512) > 0
+    assert lib.ndmps_syevj_workspace_bytes(512) >= 4 * 512 * 512 * 8
+    assert lib.ndmps_syevj_workspace_bytes(7) >= 4 * 8 * 8 * 8  # odd sizes are padded to even
+    assert lib.ndmps_compress_bond_workspace_bytes(64, 8, 64, 8, 64) > 0
+    assert lib.ndmps_reduce_workspace_bytes() > 0
+    # argument validation happens before any HIP call
+    assert lib.ndmps_sgemm(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None) == _lib.EINVAL
+    assert lib.ndmps_syevj_f64(None, 4, None, None, None, 0, None, None) == _lib.EINVAL
+    assert lib.ndmps_quantize_f32(C.c_void_p(8), 4, 0.0, 1.0, 12, C.c_void_p(8), None) == _lib.EINVAL
+    assert b"bits" in lib.ndmps_last_error()
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pkg.NDMPS.from_tensor(np.zeros((4, 4)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "img-compression-mps_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in text and "from oracle" not in text, fn
