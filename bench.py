@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Headline benchmark: Mvoxels/s of compress + reconstruct (NDMPS.from_tensor with the bond cap
+applied in the sweep, then NDMPS.to_tensor) on a synthetic 256^3 fp32 volume at chi = 64
+(BASELINE.json "metric"), input and output resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; every rank compresses and reconstructs its own volume (independent
+volumes shard with no data-path collective) -> weak scaling.  Rank 0 prints one
+JSON line.  At N=1 it also carries the CPU baseline (the NumPy oracle on the same volume, timed
+on the host cores) and the SSIM gap between the GPU and the oracle reconstruction.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=256, help="edge of the cubic volume")
+    ap.add_argument("--chi", type=int, default=64)
+    ap.add_argument("--mode", default="Std", choices=["Std", "DCT"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from imgcompressionmps_amd import NDMPS, _lib
+    from imgcompressionmps_amd.core import ndmps as ndmps_mod
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    _lib.load()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from oracle.metrics import compute_ssim_by_dim, synthetic_mri  # data generator + checker only
+
+    shape = (args.size,) * 3
+    n_vox = int(np.prod(shape))
+    x_host = synthetic_mri(shape, seed=2025 + rank)
+    x = torch.from_numpy(x_host).to(device)
+
+    def step():
+        obj = NDMPS.from_tensor(x, mode=args.mode, max_bond=args.chi)
+        rec = obj.to_tensor(as_torch=True)
+        return obj, rec
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = ndmps_mod.StageTimer()
+    ndmps_mod.set_stage_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        obj, rec = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ndmps_mod.set_stage_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stages = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
+              for k, v in timer.totals_ms().items()}
+    value = world * n_vox * args.steps / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # roofline of the reshape stage (the HBM-bound kernel north_star names): the tiled
+    # encode_permute kernel reads 4 B and writes 4 B per voxel, one launch per step.
+    perm_ms = stages.get("encode_permute", {}).get("ms_per_step", float("nan"))
+    algo_bytes = 2 * 4 * n_vox
+    achieved = algo_bytes / (perm_ms * 1e-3) / 1e9
+    roofline = {
+        "kernel": "encode_tiled_kernel<uint32>",
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None,
+        "read_frac": (4 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
+        "end_to_end_algorithmic_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9,
+    }
+
+    line = {
+        "metric": "Mvoxels/s compress+reconstruct, 256^3 fp32, bond chi=64; SSIM vs ref",
+        "value": value,
+        "unit": "Mvoxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.size}^3 fp32 synthetic MRI volume per GPU, NDMPS.from_tensor(max_bond={args.chi}, "
+                        f"mode={args.mode}) + to_tensor, device-resident in/out",
+            "volumes_per_step": world,
+            "bonds": obj.bond_sizes(),
+            "parallelism": f"{world} independent volume shard(s), no data-path collective",
+        },
+        "roofline": roofline,
+        "stages": stages,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.ndmps_oracle import OracleNDMPS
+
+        try:
+            from threadpoolctl import threadpool_info
+
+            threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        except Exception:
+            threads = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        ref = OracleNDMPS.from_tensor(x_host, mode=args.mode, max_bond=args.chi, materialise_map=False)
+        rec_ref = ref.to_tensor()
+        cpu_s = time.perf_counter() - t0
+        rec_gpu = rec.cpu().numpy().astype(np.float64)
+        x64 = x_host.astype(np.float64)
+        ssim_gpu = float(compute_ssim_by_dim(x64, rec_gpu))
+        ssim_ref = float(compute_ssim_by_dim(x64, rec_ref))
+        line["cpu_baseline"] = {
+            "value": n_vox / cpu_s / 1e6,
+            "unit": "Mvoxels/s",
+            "cores": int(threads),
+            "kind": "port",
+            "sample": f"one {args.size}^3 volume, NumPy fp64 oracle (closed-form index permutation, SVD sweep "
+                      f"with max_bond={args.chi}, chain contraction), {cpu_s:.1f} s wall",
+        }
+        line["parity"] = {
+            "ssim_gpu": ssim_gpu,
+            "ssim_oracle": ssim_ref,
+            "ssim_gap": abs(ssim_gpu - ssim_ref),
+            "rel_frobenius_vs_oracle": float(np.linalg.norm(rec_gpu - rec_ref) / np.linalg.norm(rec_ref)),
+            "max_abs_vs_oracle": float(np.abs(rec_gpu - rec_ref).max()),
+            "bonds_equal": obj.bond_sizes() == ref.bond_sizes(),
+        }
+
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,7 @@ reference is fp64 end to end (ndmps.py:56).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import gzip
 import io
@@ -33,6 +34,50 @@ from .mps import DeviceMPS
 
 _PLAN_CACHE = {}
 _DCT_CACHE = {}
+
+
+class StageTimer:
+    """Optional per-stage device timing with HIP events on the stream the kernels run on
+    (bench.py installs one with ``set_stage_timer``; ``None`` = no events recorded)."""
+
+    def __init__(self):
+        self.spans = []
+
+    @contextlib.contextmanager
+    def span(self, name):
+        torch = _torch()
+        start = torch.cuda.Event(enable_timing=True)
+        stop = torch.cuda.Event(enable_timing=True)
+        start.record()
+        try:
+            yield
+        finally:
+            stop.record()
+            self.spans.append((name, start, stop))
+
+    def totals_ms(self):
+        """{stage: (total ms, count)}; synchronises the device."""
+        _torch().cuda.synchronize()
+        out = {}
+        for name, a, b in self.spans:
+            t, c = out.get(name, (0.0, 0))
+            out[name] = (t + a.elapsed_time(b), c + 1)
+        return out
+
+    def reset(self):
+        self.spans = []
+
+
+_TIMER = None
+
+
+def set_stage_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+def _span(name):
+    return _TIMER.span(name) if _TIMER is not None else contextlib.nullcontext()
 
 
 def _torch():
@@ -134,6 +179,8 @@ class NDMPS:
             x = tensor.detach().to(device=device, dtype=torch.float32, copy=True).contiguous()
         else:
             arr = np.asarray(tensor)
+            if arr.ndim == 0:
+                raise ValueError("Shape cannot be empty.")
             if arr.dtype.kind not in "fiub":
                 raise TypeError(f"unsupported tensor dtype {arr.dtype}")
             x = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device)
@@ -156,7 +203,8 @@ class NDMPS:
                                                   _dct_basis(n, device).data_ptr(), stream))
                 x = y
             dense = torch.empty(numel, dtype=torch.float32, device=device)
-            _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), 4, stream))
+            with _span("encode_permute"):
+                _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), 4, stream))
             del x
 
             dims = [int(q) for q in plan.qubit_size]
@@ -172,8 +220,10 @@ class NDMPS:
             ws = torch.empty(int(ws_bytes.value), dtype=torch.uint8, device=device)
             bonds = (C.c_int64 * (L + 1))()
             spectra = (C.c_double * max(int(spec_off[L]), 1))()
-            _lib.check(lib.ndmps_tt_sweep_f32(dense.data_ptr(), L, cdims, float(cutoff), mb, arena.data_ptr(),
-                                              core_off, bonds, spectra, spec_off, ws.data_ptr(), ws.numel(), stream))
+            with _span("sweep"):
+                _lib.check(lib.ndmps_tt_sweep_f32(dense.data_ptr(), L, cdims, float(cutoff), mb,
+                                                  arena.data_ptr(), core_off, bonds, spectra, spec_off,
+                                                  ws.data_ptr(), ws.numel(), stream))
             del ws, dense
             cores, spec_list = [], [None] * L
             left = 1
@@ -189,8 +239,9 @@ class NDMPS:
             obj = cls(mps, plan.qubit_size.copy(), None, [[0.0, 0.0]] * L, norm, None, mode, len(shape))
             obj._shape = shape
             obj.sweep_spectra = spec_list
-            obj.update_boundary_list()
-            obj.update_norm()
+            with _span("state"):
+                obj.update_boundary_list()
+                obj.update_norm()
         return obj
 
     # ----------------------------------------------------------------- bookkeeping
@@ -269,9 +320,11 @@ class NDMPS:
         with torch.cuda.device(device):
             plan = _plan_for(self._shape, device.index or 0)
             stream = _lib.stream_ptr()
-            dense = self.mps.to_dense()
+            with _span("chain"):
+                dense = self.mps.to_dense()
             out = torch.empty(self._shape, dtype=torch.float32, device=device)
-            _lib.check(lib.ndmps_decode_permute(plan.handle, dense.data_ptr(), out.data_ptr(), 4, stream))
+            with _span("decode_permute"):
+                _lib.check(lib.ndmps_decode_permute(plan.handle, dense.data_ptr(), out.data_ptr(), 4, stream))
             if self.mode == "DCT":
                 n = self._shape[-1]
                 rec = torch.empty_like(out)
