@@ -8,8 +8,9 @@
 // sweep, n/2 disjoint rotations per step, all applied at once: G' = J^T G J, V' = V J.
 // One kernel per step, one thread per (row pair, column pair) 2x2 block, ping-pong
 // buffers so a step never reads what it writes.  The host reads one counter per sweep.
-// Latency-bound (n-1 dependent launches per sweep); the block variant that works on
-// LDS-resident 2b x 2b sub-problems is in eig_block.hip.
+// Latency-bound (n-1 dependent launches per sweep).  This is the simple reference solver
+// (ndmps_syevj_simple_f64), kept to cross-check the block solver of eig_block.hip, which is
+// what ndmps_syevj_f64 and the sweep use.
 #include <math.h>
 
 #include <algorithm>
@@ -196,12 +197,12 @@ constexpr int kMaxSweeps = 40;
 
 }  // namespace
 
-extern "C" int64_t ndmps_syevj_workspace_bytes(int64_t n) {
+extern "C" int64_t ndmps_syevj_simple_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
   return syevj_layout(n).total;
 }
 
-extern "C" int ndmps_syevj_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
+extern "C" int ndmps_syevj_simple_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
                                int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_G && d_V && d_w, "NULL eigen operand");
   NDMPS_REQUIRE(n >= 1 && n <= 32768, "eigen size n=%lld outside [1, 32768]", (long long)n);

@@ -110,12 +110,17 @@ int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const d
 int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n);
 int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
                    void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
-/* symmetric eigen-decomposition (two-sided parallel Jacobi, fp64): G = V diag(w) V^T,
+/* symmetric eigen-decomposition (block two-sided Jacobi, fp64): G = V diag(w) V^T,
  * w descending, eigenvectors in the COLUMNS of V, each with its largest-magnitude
  * component positive.  d_G is destroyed.  Synchronises the stream. */
 int64_t ndmps_syevj_workspace_bytes(int64_t n);
 int ndmps_syevj_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
                     int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
+/* same contract, scalar-parallel Jacobi (one launch per rotation step); kept as the
+ * cross-check of the block solver above */
+int64_t ndmps_syevj_simple_workspace_bytes(int64_t n);
+int ndmps_syevj_simple_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
+                           int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * MPS sweep: replaces quimb MatrixProductState.from_dense (core/ndmps.py:74).

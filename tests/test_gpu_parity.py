@@ -180,6 +180,36 @@ def test_gram_fp64(m, n):
     assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
 
 
+def _syevj(lib, g, simple=False):
+    n = g.shape[0]
+    tg = dev(g)
+    v = torch.empty((n, n), dtype=torch.float64, device=DEV)
+    w = torch.empty(n, dtype=torch.float64, device=DEV)
+    size_fn, fn = ((lib.ndmps_syevj_simple_workspace_bytes, lib.ndmps_syevj_simple_f64) if simple
+                   else (lib.ndmps_syevj_workspace_bytes, lib.ndmps_syevj_f64))
+    nbytes = size_fn(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    sweeps = C.c_int()
+    _lib.check(fn(tg.data_ptr(), n, v.data_ptr(), w.data_ptr(), ws.data_ptr(), nbytes, C.byref(sweeps), sp()))
+    return w.cpu().numpy(), v.cpu().numpy(), sweeps.value
+
+
+@pytest.mark.parametrize("n", [5, 32, 40, 96, 512])
+def test_block_and_simple_jacobi_agree(n):
+    lib = _lib.load()
+    rng = np.random.default_rng(100 + n)
+    a = rng.standard_normal((2 * n, n)) * np.logspace(0, -5, n)[None, :]
+    g = a.T @ a
+    wb, vb, sb = _syevj(lib, g)
+    ws_, vs, ss = _syevj(lib, g, simple=True)
+    ref = np.linalg.eigvalsh(g)[::-1]
+    for w, v in ((wb, vb), (ws_, vs)):
+        assert np.abs(w - ref).max() <= 2e-15 * max(n, 50) * ref[0]
+        assert np.abs(v.T @ v - np.eye(n)).max() <= 2e-15 * max(n, 50)
+        assert np.abs(g @ v - v * w[None, :]).max() <= 2e-15 * max(n, 50) * ref[0]
+    assert sb <= 20 and ss <= 24
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 33, 64, 130, 256])
 def test_syevj_against_lapack(n):
     lib = _lib.load()
