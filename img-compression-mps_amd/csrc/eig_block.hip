@@ -54,17 +54,42 @@ __device__ __forceinline__ void circle_pair(int k, int step, int count, int& a, 
   }
 }
 
+// 1/sqrt(x) and 1/x for x in a safe range: hardware estimate + two Newton steps (the
+// compiler's IEEE expansions of fp64 sqrt/div cost several hundred dependent cycles each,
+// and the rotation is the serial part of every inner step).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * fma(-x, y, 2.0);
+  y = y * fma(-x, y, 2.0);
+  return y;
+}
+
+// Jacobi rotation zeroing a_pq: t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = (aqq-app)/(2apq),
+// evaluated as t = sgn(a b) |b| / (|a| + hypot(a, b)) with a = aqq - app, b = 2 apq scaled by a
+// power of two (one rsqrt, one rcp), then c = rsqrt(1 + t^2), s = t c.
 __device__ __forceinline__ void rotation64(double app, double aqq, double apq, double tol_rot, double& c,
                                            double& s, double& t) {
-  if (fabs(apq) <= tol_rot) {
+  if (!(fabs(apq) > tol_rot)) {
     c = 1.0;
     s = 0.0;
     t = 0.0;
     return;
   }
-  const double tau = (aqq - app) / (2.0 * apq);
-  t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-  c = 1.0 / sqrt(1.0 + t * t);
+  const double a = aqq - app, b = 2.0 * apq;
+  int e;
+  (void)frexp(fmax(fabs(a), fabs(b)), &e);
+  const double as = ldexp(fabs(a), -e), bs = ldexp(fabs(b), -e);  // max of the two in [0.5, 1)
+  const double h2 = fma(as, as, bs * bs);
+  const double h = h2 * fast_rsqrt(h2);
+  const double mag = bs * fast_rcp(as + h);
+  t = ((a < 0.0) != (b < 0.0)) ? -mag : mag;
+  c = fast_rsqrt(fma(t, t, 1.0));
   s = t * c;
 }
 

@@ -260,6 +260,7 @@ gram_partial_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t l
   for (int e = tid; e < TS * TS; e += 256) out[e] = red[e / TS][e % TS];
 }
 
+// grid: (n_tiles, TS*TS/256); one thread per tile element, slabs summed in fixed order
 template <int T>
 __global__ void __launch_bounds__(256)
 gram_reduce_kernel(const double* __restrict__ partial, double* __restrict__ G, int64_t n,
@@ -271,21 +272,23 @@ gram_reduce_kernel(const double* __restrict__ partial, double* __restrict__ G, i
     ++ti;
   }
   const int tj = ti + tile;
-  for (int e = threadIdx.x; e < TS * TS; e += 256) {
-    double s = 0.0;
-    for (int sl = 0; sl < n_slabs; ++sl)
-      s += partial[((int64_t)sl * n_tiles + blockIdx.x) * (TS * TS) + e];
-    const int64_t r = (int64_t)ti * TS + e / TS, c = (int64_t)tj * TS + e % TS;
-    if (r < n && c < n) {
-      if (ti == tj) {
-        if (c >= r) {  // keep the diagonal tile exactly symmetric
-          G[r * n + c] = s;
-          G[c * n + r] = s;
-        }
-      } else {
-        G[r * n + c] = s;
-        G[c * n + r] = s;
-      }
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= TS * TS) return;
+  const double* src = partial + (int64_t)blockIdx.x * (TS * TS) + e;
+  const int64_t slab_stride = (int64_t)n_tiles * (TS * TS);
+  double s = 0.0;
+  int sl = 0;
+  for (; sl + 4 <= n_slabs; sl += 4) {
+    const double v0 = src[(sl + 0) * slab_stride], v1 = src[(sl + 1) * slab_stride];
+    const double v2 = src[(sl + 2) * slab_stride], v3 = src[(sl + 3) * slab_stride];
+    s = (((s + v0) + v1) + v2) + v3;
+  }
+  for (; sl < n_slabs; ++sl) s += src[sl * slab_stride];
+  const int64_t r = (int64_t)ti * TS + e / TS, c = (int64_t)tj * TS + e % TS;
+  if (r < n && c < n) {
+    if (ti != tj || c >= r) {  // diagonal tiles: upper part mirrored, so G is exactly symmetric
+      G[r * n + c] = s;
+      G[c * n + r] = s;
     }
   }
 }
@@ -364,8 +367,8 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
   do {                                                                                              \
     hipLaunchKernelGGL(gram_partial_kernel<TT>, grid, dim3(256), 0, s, d_A, m, n, lda, partial,     \
                        g.tiles_1d, g.rows_per_slab);                                                \
-    hipLaunchKernelGGL(gram_reduce_kernel<TT>, dim3(g.n_tiles), dim3(256), 0, s, partial, d_G, n,   \
-                       g.tiles_1d, g.n_tiles, g.n_slabs);                                           \
+    hipLaunchKernelGGL(gram_reduce_kernel<TT>, dim3(g.n_tiles, (16 * TT * 16 * TT + 255) / 256),   \
+                       dim3(256), 0, s, partial, d_G, n, g.tiles_1d, g.n_tiles, g.n_slabs);         \
   } while (0)
   if (g.T == 1) NDMPS_GRAM(1);
   else if (g.T == 2) NDMPS_GRAM(2);
