@@ -1,0 +1,153 @@
+"""Lists of volumes: the caller side of the hot path, sharded over GPUs.
+
+The reference treats a batch as a Python loop over independent tensors
+(src/imgcompressionmps/evaluation/benchmark.py:58-77 ``conv_to_mps``, :80-100
+``conv_to_tensors``, :103-118 ``compress_list``).  Independent volumes are the unit of
+multi-GPU parallelism: one process per GPU, every rank encodes / truncates /
+reconstructs its own shard, and there is NO collective on the data path.  The only
+communication is optional and off the critical path: gathering the (small) cores or the
+reconstructed volumes to every rank with RCCL all_gather (``backend="nccl"`` on ROCm),
+or with gloo on CPU tensors in the tests.
+
+Same function names and argument meaning as the reference where one exists.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+
+
+def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
+    """Block partition of ``range(n_items)``: rank r owns a contiguous run, sizes differ by
+    at most one, concatenating the shards in rank order restores the original order."""
+    if world_size < 1 or not (0 <= rank < world_size) or n_items < 0:
+        raise ValueError("bad shard request")
+    base, extra = divmod(n_items, world_size)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+def conv_to_mps(tensor_list: Sequence, mode: str = "Std", norm: bool = False, max_bond=None,
+                cutoff: float = 1e-10, device=None):
+    """benchmark.py:58-77: encode every tensor of the (local) list."""
+    from .ndmps import NDMPS
+
+    return [NDMPS.from_tensor(t, norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff, device=device)
+            for t in tensor_list]
+
+
+def conv_to_tensors(mps_list: Sequence, as_torch: bool = False):
+    """benchmark.py:80-100: reconstruct every NDMPS of the (local) list."""
+    return [m.to_tensor(as_torch=as_torch) for m in mps_list]
+
+
+def compress_list(mps_list: Sequence, cutoff: float, max_bond=None) -> None:
+    """benchmark.py:103-118: in-place truncation of every NDMPS of the (local) list."""
+    for m in mps_list:
+        m.compress(cutoff, max_bond=max_bond)
+
+
+# ------------------------------------------------------------------------ collectives
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+def pack_cores(core_tensors: Sequence):
+    """Flatten a list of core tensors into (flat fp32 tensor, int64 shape table (n, 3))."""
+    import torch
+
+    shapes = torch.tensor([list(c.shape) for c in core_tensors], dtype=torch.int64).reshape(-1, 3)
+    flat = torch.cat([c.reshape(-1).to(torch.float32) for c in core_tensors]) if len(core_tensors) else \
+        torch.zeros(0, dtype=torch.float32)
+    return flat, shapes
+
+
+def unpack_cores(flat, shapes):
+    out, off = [], 0
+    for s in shapes.tolist():
+        n = int(np.prod(s))
+        out.append(flat[off:off + n].reshape(*s))
+        off += n
+    return out
+
+
+def all_gather_cores(local_cores: Sequence[Sequence], group=None):
+    """Every rank receives the cores of every volume, in global volume order.
+
+    ``local_cores``: for each local volume, its list of (chi, d, chi') tensors (CPU tensors with
+    gloo, device tensors with nccl/RCCL).  Cores are tiny (<= ~1.4 % of a volume), so
+    this is two small all_gathers: the shape tables, then the padded flat payloads.
+    """
+    import torch
+
+    dist = _dist()
+    world = dist.get_world_size(group)
+    dev = local_cores[0][0].device if local_cores and local_cores[0] else torch.device("cpu")
+    flat_parts, shape_parts, counts = [], [], []
+    for cores in local_cores:
+        f, s = pack_cores(cores)
+        flat_parts.append(f.to(dev))
+        shape_parts.append(s.to(dev))
+        counts.append(len(cores))
+    flat = torch.cat(flat_parts) if flat_parts else torch.zeros(0, dtype=torch.float32, device=dev)
+    shapes = torch.cat(shape_parts) if shape_parts else torch.zeros((0, 3), dtype=torch.int64, device=dev)
+    counts_t = torch.tensor(counts, dtype=torch.int64, device=dev)
+
+    # exchange sizes: [n_volumes, n_cores, n_elements]
+    meta = torch.tensor([len(counts), shapes.shape[0], flat.numel()], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    max_vol = max(int(m[0]) for m in metas)
+    max_cores = max(int(m[1]) for m in metas)
+    max_elems = max(int(m[2]) for m in metas)
+
+    def padded(t, n, fill_shape):
+        buf = torch.zeros((n,) + fill_shape, dtype=t.dtype, device=dev)
+        buf[: t.shape[0]] = t
+        return buf
+
+    g_counts = [torch.zeros(max_vol, dtype=torch.int64, device=dev) for _ in range(world)]
+    g_shapes = [torch.zeros((max_cores, 3), dtype=torch.int64, device=dev) for _ in range(world)]
+    g_flat = [torch.zeros(max_elems, dtype=torch.float32, device=dev) for _ in range(world)]
+    dist.all_gather(g_counts, padded(counts_t, max_vol, ()), group=group)
+    dist.all_gather(g_shapes, padded(shapes, max_cores, (3,)), group=group)
+    dist.all_gather(g_flat, padded(flat, max_elems, ()), group=group)
+
+    result = []
+    for r in range(world):
+        n_vol, n_cores, n_el = (int(v) for v in metas[r])
+        cores = unpack_cores(g_flat[r][:n_el], g_shapes[r][:n_cores])
+        off = 0
+        for c in g_counts[r][:n_vol].tolist():
+            result.append(cores[off:off + c])
+            off += c
+    return result
+
+
+def all_gather_volumes(local_volumes: Sequence, n_total: int, group=None):
+    """Every rank receives every reconstructed volume (same shape), in global order."""
+    import torch
+
+    dist = _dist()
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per_rank = [len(shard_indices(n_total, r, world)) for r in range(world)]
+    if len(local_volumes) != per_rank[rank]:
+        raise ValueError("local shard does not match shard_indices")
+    width = max(per_rank)
+    ref = local_volumes[0] if local_volumes else None
+    shape_t = torch.tensor(list(ref.shape) if ref is not None else [], dtype=torch.int64)
+    if ref is None:
+        raise ValueError("all_gather_volumes needs at least one local volume per rank")
+    buf = torch.zeros((width,) + tuple(ref.shape), dtype=ref.dtype, device=ref.device)
+    for i, v in enumerate(local_volumes):
+        buf[i] = v
+    gathered = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    out = []
+    for r in range(world):
+        out.extend(gathered[r][i] for i in range(per_rank[r]))
+    return out
