@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--size", type=int, default=256, help="edge of the cubic volume")
     ap.add_argument("--chi", type=int, default=64)
     ap.add_argument("--mode", default="Std", choices=["Std", "DCT"])
+    ap.add_argument("--batch", type=int, default=8, help="independent volumes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -64,13 +65,21 @@ def main():
 
     shape = (args.size,) * 3
     n_vox = int(np.prod(shape))
+    # one batch of independent volumes per GPU (seeded, distinct per rank and per slot)
     x_host = synthetic_mri(shape, seed=2025 + rank)
-    x = torch.from_numpy(x_host).to(device)
+    xs = [torch.from_numpy(x_host).to(device)]
+    for j in range(1, args.batch):
+        xs.append(torch.from_numpy(synthetic_mri(shape, seed=2025 + 1000 * j + rank)).to(device))
+    x = xs[0]
 
     def step():
-        obj = NDMPS.from_tensor(x, mode=args.mode, max_bond=args.chi)
-        rec = obj.to_tensor(as_torch=True)
-        return obj, rec
+        objs = NDMPS.from_tensors(xs, mode=args.mode, max_bond=args.chi)
+        recs = [o.to_tensor(as_torch=True) for o in objs]
+        return objs[0], recs[0]
+
+    def single_step():
+        o = NDMPS.from_tensor(x, mode=args.mode, max_bond=args.chi)
+        return o, o.to_tensor(as_torch=True)
 
     def barrier():
         if world > 1:
@@ -95,12 +104,22 @@ def main():
 
     stages = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
               for k, v in timer.totals_ms().items()}
-    value = world * n_vox * args.steps / elapsed / 1e6
+    value = world * args.batch * n_vox * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
+
+    # single-volume latency (batch of one), same kernels; not part of `value`
+    single_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        single_step()
+    torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t0) / 3 * 1e3
 
     # roofline of the reshape stage (the HBM-bound kernel north_star names): the tiled
     # encode_permute kernel reads 4 B and writes 4 B per voxel, one launch per step.
-    perm_ms = stages.get("encode_permute", {}).get("ms_per_step", float("nan"))
+    perm = stages.get("encode_permute", {})
+    perm_ms = perm.get("ms_per_step", float("nan")) / max(perm.get("launches_per_step", 1.0), 1.0)
     algo_bytes = 2 * 4 * n_vox
     achieved = algo_bytes / (perm_ms * 1e-3) / 1e9
     roofline = {
@@ -112,7 +131,7 @@ def main():
         "frac": achieved / HBM_PEAK_GBPS,
         "traffic": None,
         "read_frac": (4 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
-        "end_to_end_algorithmic_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9,
+        "end_to_end_algorithmic_GBps": args.batch * algo_bytes / (ms_per_step * 1e-3) / 1e9,
     }
 
     line = {
@@ -129,14 +148,17 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.size}^3 fp32 synthetic MRI volume per GPU, NDMPS.from_tensor(max_bond={args.chi}, "
-                        f"mode={args.mode}) + to_tensor, device-resident in/out",
-            "volumes_per_step": world,
+            "workload": f"batch of {args.batch} independent {args.size}^3 fp32 synthetic MRI volumes per GPU per step, "
+                        f"NDMPS.from_tensors(max_bond={args.chi}, mode={args.mode}) + to_tensor each, "
+                        f"device-resident in/out",
+            "volumes_per_step": world * args.batch,
+            "batch_per_gpu": args.batch,
             "bonds": obj.bond_sizes(),
             "parallelism": f"{world} independent volume shard(s), no data-path collective",
         },
         "roofline": roofline,
         "stages": stages,
+        "single_volume": {"ms": single_ms, "Mvoxels_per_s": n_vox / single_ms / 1e3},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

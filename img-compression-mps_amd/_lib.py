@@ -38,6 +38,8 @@ SIGNATURES = {
     "ndmps_idct_last_f32": (C.c_int, [vp, vp, i64, i64, vp, vp]),
     "ndmps_sumsq_f32": (C.c_int, [vp, i64, p_f64, vp, i64, vp]),
     "ndmps_minmax_f32": (C.c_int, [vp, i64, p_f32, p_f32, vp, i64, vp]),
+    "ndmps_minmax_many_workspace_bytes": (i64, [C.c_int]),
+    "ndmps_minmax_many_f32": (C.c_int, [C.c_int, C.POINTER(vp), p_i64, p_f32, vp, i64, vp]),
     "ndmps_scale_f32": (C.c_int, [vp, i64, C.c_double, vp]),
     "ndmps_reduce_workspace_bytes": (i64, []),
     "ndmps_sgemm": (C.c_int, [C.c_int, C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp]),
@@ -46,8 +48,14 @@ SIGNATURES = {
     "ndmps_gram_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, i64, vp]),
     "ndmps_syevj_workspace_bytes": (i64, [i64]),
     "ndmps_syevj_f64": (C.c_int, [vp, i64, vp, vp, vp, i64, p_int, vp]),
+    "ndmps_syevj_batched_workspace_bytes": (i64, [i64, C.c_int]),
+    "ndmps_syevj_batched_f64": (C.c_int, [C.c_int, vp, i64, p_i64, vp, i64, vp, i64, vp, i64, p_int, vp]),
+    "ndmps_tt_sweep_batched_workspace_bytes": (i64, [C.c_int, C.c_int, p_i64, i64]),
+    "ndmps_tt_sweep_batched_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
+                                             C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, i64, vp]),
     "ndmps_syevj_simple_workspace_bytes": (i64, [i64]),
     "ndmps_syevj_simple_f64": (C.c_int, [vp, i64, vp, vp, vp, i64, p_int, vp]),
+    "ndmps_debug_diag_stamps": (C.c_int, [vp, C.c_int, vp, i64, C.POINTER(C.c_uint64), C.c_int, vp]),
     "ndmps_tt_layout": (C.c_int, [C.c_int, p_i64, i64, p_i64, p_i64, p_i64, p_i64]),
     "ndmps_tt_sweep_f32": (C.c_int, [vp, C.c_int, p_i64, C.c_double, i64, vp, p_i64, p_i64, p_f64,
                                      p_i64, vp, i64, vp]),

@@ -169,43 +169,70 @@ class NDMPS:
         max_bond : optional bond cap chi applied during the sweep (None = exact sweep).
         cutoff : relative singular-value cutoff of the sweep (quimb from_dense default).
         """
+        return cls.from_tensors([tensor], norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff,
+                                device=device)[0]
+
+    @classmethod
+    def from_tensors(cls, tensors, norm: bool = False, mode: str = "Std", max_bond=None,
+                     cutoff: float = 1e-10, device=None):
+        """
+        Encode a list of independent tensors OF THE SAME SHAPE in one batched pass (what the
+        reference does with a Python loop, evaluation/benchmark.py:73-76).  The volumes go through
+        the sites in lockstep, so each site's eigenproblems are solved by one batched launch
+        sequence; results are identical to calling ``from_tensor`` on each.
+        """
         torch = _torch()
         _lib.require_device()
         lib = _lib.load()
+        tensors = list(tensors)
+        if not tensors:
+            return []
+        first = tensors[0]
         if device is None:
-            device = tensor.device if isinstance(tensor, torch.Tensor) and tensor.is_cuda else "cuda"
+            device = first.device if isinstance(first, torch.Tensor) and first.is_cuda else "cuda"
         device = torch.device(device)
-        if isinstance(tensor, torch.Tensor):
-            x = tensor.detach().to(device=device, dtype=torch.float32, copy=True).contiguous()
-        else:
-            arr = np.asarray(tensor)
-            if arr.ndim == 0:
-                raise ValueError("Shape cannot be empty.")
-            if arr.dtype.kind not in "fiub":
-                raise TypeError(f"unsupported tensor dtype {arr.dtype}")
-            x = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device)
-        shape = tuple(int(s) for s in x.shape)
-        if len(shape) == 0:
-            raise ValueError("Shape cannot be empty.")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        xs = []
+        for tensor in tensors:
+            if isinstance(tensor, torch.Tensor):
+                if tensor.dim() == 0:
+                    raise ValueError("Shape cannot be empty.")
+                x = tensor.detach().to(device=device, dtype=torch.float32, copy=True).contiguous()
+            else:
+                arr = np.asarray(tensor)
+                if arr.ndim == 0:
+                    raise ValueError("Shape cannot be empty.")
+                if arr.dtype.kind not in "fiub":
+                    raise TypeError(f"unsupported tensor dtype {arr.dtype}")
+                x = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device)
+            xs.append(x)
+        shape = tuple(int(v) for v in xs[0].shape)
+        if any(tuple(x.shape) != shape for x in xs):
+            raise ValueError("from_tensors needs tensors of one shape; encode other shapes separately")
+        batch = len(xs)
         with torch.cuda.device(device):
-            plan = _plan_for(shape, device.index or 0)
+            plan = _plan_for(shape, device.index)
             stream = _lib.stream_ptr()
             numel = plan.numel
-            if norm:
-                ws = torch.empty(lib.ndmps_reduce_workspace_bytes(), dtype=torch.uint8, device=device)
-                ss = C.c_double()
-                _lib.check(lib.ndmps_sumsq_f32(x.data_ptr(), numel, C.byref(ss), ws.data_ptr(), ws.numel(), stream))
-                _lib.check(lib.ndmps_scale_f32(x.data_ptr(), numel, 1.0 / float(np.sqrt(ss.value)), stream))
-            if mode == "DCT":
-                n = shape[-1]
-                y = torch.empty_like(x)
-                _lib.check(lib.ndmps_dct_last_f32(x.data_ptr(), y.data_ptr(), numel // n, n,
-                                                  _dct_basis(n, device).data_ptr(), stream))
-                x = y
-            dense = torch.empty(numel, dtype=torch.float32, device=device)
-            with _span("encode_permute"):
-                _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), 4, stream))
-            del x
+            denses = []
+            for x in xs:
+                if norm:
+                    ws = torch.empty(lib.ndmps_reduce_workspace_bytes(), dtype=torch.uint8, device=device)
+                    ss = C.c_double()
+                    _lib.check(lib.ndmps_sumsq_f32(x.data_ptr(), numel, C.byref(ss), ws.data_ptr(), ws.numel(), stream))
+                    _lib.check(lib.ndmps_scale_f32(x.data_ptr(), numel, 1.0 / float(np.sqrt(ss.value)), stream))
+                if mode == "DCT":
+                    n = shape[-1]
+                    y = torch.empty_like(x)
+                    _lib.check(lib.ndmps_dct_last_f32(x.data_ptr(), y.data_ptr(), numel // n, n,
+                                                      _dct_basis(n, device).data_ptr(), stream))
+                    x = y
+                dense = torch.empty(numel, dtype=torch.float32, device=device)
+                with _span("encode_permute"):
+                    _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), 4, stream))
+                denses.append(dense)
+            del xs, x
 
             dims = [int(q) for q in plan.qubit_size]
             L = len(dims)
@@ -214,40 +241,54 @@ class NDMPS:
             max_bonds = (C.c_int64 * (L + 1))()
             core_off = (C.c_int64 * (L + 1))()
             spec_off = (C.c_int64 * (L + 1))()
-            ws_bytes = C.c_int64()
-            _lib.check(lib.ndmps_tt_layout(L, cdims, mb, max_bonds, core_off, spec_off, C.byref(ws_bytes)))
-            arena = torch.empty(int(core_off[L]), dtype=torch.float32, device=device)
-            ws = torch.empty(int(ws_bytes.value), dtype=torch.uint8, device=device)
-            bonds = (C.c_int64 * (L + 1))()
-            spectra = (C.c_double * max(int(spec_off[L]), 1))()
+            _lib.check(lib.ndmps_tt_layout(L, cdims, mb, max_bonds, core_off, spec_off, None))
+            ws_bytes = lib.ndmps_tt_sweep_batched_workspace_bytes(batch, L, cdims, mb)
+            if ws_bytes < 0:
+                _lib.check(_lib.EINVAL)
+            arenas = [torch.empty(int(core_off[L]), dtype=torch.float32, device=device) for _ in range(batch)]
+            ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=device)
+            bonds = (C.c_int64 * (batch * (L + 1)))()
+            spec_total = int(spec_off[L])
+            spectra = (C.c_double * max(batch * spec_total, 1))()
+            dense_ptrs = (C.c_void_p * batch)(*[d.data_ptr() for d in denses])
+            arena_ptrs = (C.c_void_p * batch)(*[a.data_ptr() for a in arenas])
             with _span("sweep"):
-                _lib.check(lib.ndmps_tt_sweep_f32(dense.data_ptr(), L, cdims, float(cutoff), mb,
-                                                  arena.data_ptr(), core_off, bonds, spectra, spec_off,
-                                                  ws.data_ptr(), ws.numel(), stream))
-            del ws, dense
-            cores, spec_list = [], [None] * L
-            left = 1
-            for i in range(L):
-                k0, k1 = int(bonds[i]), int(bonds[i + 1])
-                n_el = k0 * dims[i] * k1
-                cores.append(arena[int(core_off[i]): int(core_off[i]) + n_el].view(k0, dims[i], k1).clone())
-                if i >= 1:
-                    cnt = min(left, dims[i] * k1)
-                    spec_list[i] = np.array(spectra[int(spec_off[i]): int(spec_off[i]) + cnt])
-                left *= dims[i]
-            mps = DeviceMPS(cores)
-            obj = cls(mps, plan.qubit_size.copy(), None, [[0.0, 0.0]] * L, norm, None, mode, len(shape))
-            obj._shape = shape
-            obj.sweep_spectra = spec_list
+                _lib.check(lib.ndmps_tt_sweep_batched_f32(batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs,
+                                                          core_off, bonds, spectra, spec_off, ws.data_ptr(),
+                                                          ws.numel(), stream))
+            del ws, denses
+            objs = []
+            for b in range(batch):
+                cores, spec_list = [], [None] * L
+                left = 1
+                for i in range(L):
+                    k0, k1 = int(bonds[b * (L + 1) + i]), int(bonds[b * (L + 1) + i + 1])
+                    n_el = k0 * dims[i] * k1
+                    view = arenas[b][int(core_off[i]): int(core_off[i]) + n_el].view(k0, dims[i], k1)
+                    # truncated arenas are compact, keep the views; exact sweeps own worst-case arenas
+                    cores.append(view if mb else view.clone())
+                    if i >= 1:
+                        cnt = min(left, dims[i] * k1)
+                        base = b * spec_total + int(spec_off[i])
+                        spec_list[i] = np.array(spectra[base: base + cnt])
+                    left *= dims[i]
+                obj = cls(DeviceMPS(cores), plan.qubit_size.copy(), None, [[0.0, 0.0]] * L, norm, None, mode,
+                          len(shape))
+                obj._shape = shape
+                obj.sweep_spectra = spec_list
+                objs.append(obj)
             with _span("state"):
-                obj.update_boundary_list()
-                obj.update_norm()
-        return obj
+                all_cores = [c for o in objs for c in o.mps.cores]
+                mm = _ft.minmax_many(all_cores)
+                for b, o in enumerate(objs):
+                    o.boundary_list = np.array([list(v) for v in mm[b * L:(b + 1) * L]])
+                    o.update_norm()
+        return objs
 
     # ----------------------------------------------------------------- bookkeeping
     def update_boundary_list(self):
         """Recompute min/max boundaries for each MPS tensor."""
-        self.boundary_list = np.array([list(_ft.minmax(c)) for c in self.mps.cores])
+        self.boundary_list = np.array([list(v) for v in _ft.minmax_many(self.mps.cores)])
 
     def update_norm(self):
         """Update stored norm of the current MPS."""

@@ -7,6 +7,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -104,6 +105,34 @@ __global__ void __launch_bounds__(256) minmax_final_kernel(const float* __restri
   }
 }
 
+// many small tensors at once: blockIdx.y = tensor, blockIdx.x = slice; partial (min, max) per slice
+__global__ void __launch_bounds__(256)
+minmax_many_kernel(const float* const* __restrict__ ptrs, const int64_t* __restrict__ lens,
+                   float* __restrict__ partial) {
+  __shared__ float rmin[4], rmax[4];
+  const float* x = ptrs[blockIdx.y];
+  const int64_t n = lens[blockIdx.y];
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float v = x[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if ((threadIdx.x & 63) == 0) {
+    rmin[threadIdx.x >> 6] = lo;
+    rmax[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = partial + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3]));
+    o[1] = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+  }
+}
+
 __global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, int64_t n, double factor) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
@@ -190,6 +219,45 @@ extern "C" int ndmps_minmax_f32(const float* d_x, int64_t n, float* h_min, float
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   *h_min = host[0];
   *h_max = host[1];
+  return NDMPS_OK;
+}
+
+constexpr int kManySlices = 16;
+
+extern "C" int64_t ndmps_minmax_many_workspace_bytes(int count) {
+  if (count <= 0) return 0;
+  return (int64_t)count * (8 + 8 + 2 * 4 * kManySlices) + 1024;
+}
+
+extern "C" int ndmps_minmax_many_f32(int count, const float* const* h_ptrs, const int64_t* h_lens,
+                                     float* h_out, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(count >= 1 && count <= 65535 && h_ptrs && h_lens && h_out, "bad minmax_many argument");
+  if (!d_ws || ws_bytes < ndmps_minmax_many_workspace_bytes(count)) {
+    ndmps::set_error("minmax_many workspace too small");
+    return NDMPS_EWORKSPACE;
+  }
+  for (int i = 0; i < count; ++i) NDMPS_REQUIRE(h_ptrs[i] && h_lens[i] > 0, "tensor %d is empty or NULL", i);
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)d_ws;
+  const float** d_ptrs = (const float**)base;
+  int64_t* d_lens = (int64_t*)(base + ndmps::round_up((int64_t)count * 8, 256));
+  float* partial = (float*)((char*)d_lens + ndmps::round_up((int64_t)count * 8, 256));
+  NDMPS_CHECK_HIP(hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(float*) * count, hipMemcpyHostToDevice, s));
+  NDMPS_CHECK_HIP(hipMemcpyAsync(d_lens, h_lens, sizeof(int64_t) * count, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(minmax_many_kernel, dim3(kManySlices, count), dim3(256), 0, s, d_ptrs, d_lens, partial);
+  NDMPS_LAUNCH_CHECK();
+  std::vector<float> host((size_t)count * kManySlices * 2);
+  NDMPS_CHECK_HIP(hipMemcpyAsync(host.data(), partial, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < count; ++i) {
+    float lo = FLT_MAX, hi = -FLT_MAX;
+    for (int j = 0; j < kManySlices; ++j) {
+      lo = std::min(lo, host[2 * ((size_t)i * kManySlices + j)]);
+      hi = std::max(hi, host[2 * ((size_t)i * kManySlices + j) + 1]);
+    }
+    h_out[2 * i] = lo;
+    h_out[2 * i + 1] = hi;
+  }
   return NDMPS_OK;
 }
 

@@ -112,11 +112,12 @@ struct SweepLayout {
   int64_t small_max = 1;      // largest eigenproblem
   int64_t gram_ws = 0;        // largest Gram workspace
   int64_t wide_elems = 0;     // largest wide unfolding (m < n), elements
-  int64_t workspace = 0;
+  int64_t workspace = 0;      // for the batch size it was computed for
 };
 
-int sweep_layout(int L, const int64_t* dims, int64_t max_bond, SweepLayout& out) {
+int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepLayout& out) {
   NDMPS_REQUIRE(L >= 1 && L <= 64, "L=%d outside [1, 64]", L);
+  NDMPS_REQUIRE(batch >= 1 && batch <= 4096, "batch=%d outside [1, 4096]", batch);
   out.numel = 1;
   for (int i = 0; i < L; ++i) {
     NDMPS_REQUIRE(dims[i] >= 1, "dims[%d]=%lld must be positive", i, (long long)dims[i]);
@@ -144,16 +145,17 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, SweepLayout& out)
       else out.wide_elems = std::max(out.wide_elems, m * n);
     }
   }
+  const int64_t sq = out.small_max * out.small_max;
   int64_t used = 0;
-  used = arena_bytes(used, 4, out.numel);                              // second carry buffer
-  used = arena_bytes(used, 8, out.small_max * out.small_max);          // G
-  used = arena_bytes(used, 8, out.small_max * out.small_max);          // V / U
-  used = arena_bytes(used, 8, out.small_max);                          // w
-  used = arena_bytes(used, 8, out.small_max);                          // sigma
-  used = arena_bytes(used, 1, ndmps_syevj_workspace_bytes(out.small_max));
-  used = arena_bytes(used, 1, out.gram_ws);
-  used = arena_bytes(used, 8, out.wide_elems);                         // A64
-  used = arena_bytes(used, 8, out.wide_elems);                         // U_k^T A64
+  used = arena_bytes(used, 4, (int64_t)batch * out.numel);              // second carry buffer per volume
+  used = arena_bytes(used, 8, (int64_t)batch * sq);                     // G
+  used = arena_bytes(used, 8, (int64_t)batch * sq);                     // V / U
+  used = arena_bytes(used, 8, (int64_t)batch * out.small_max);          // w
+  used = arena_bytes(used, 8, (int64_t)batch * out.small_max);          // sigma
+  used = arena_bytes(used, 1, ndmps_syevj_batched_workspace_bytes(out.small_max, batch));
+  used = arena_bytes(used, 1, out.gram_ws);                             // shared, stream-ordered
+  used = arena_bytes(used, 8, (int64_t)batch * out.wide_elems);         // A64 per volume
+  used = arena_bytes(used, 8, out.wide_elems);                          // U_k^T A64, shared
   out.workspace = ndmps::round_up(used, 256) + 256;
   return NDMPS_OK;
 }
@@ -165,7 +167,7 @@ extern "C" int ndmps_tt_layout(int L, const int64_t* h_dims, int64_t max_bond, i
                                int64_t* h_workspace_bytes) {
   NDMPS_REQUIRE(h_dims, "NULL dims");
   SweepLayout lay;
-  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, lay));
+  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, 1, lay));
   for (int i = 0; i <= L; ++i) {
     if (h_max_bonds) h_max_bonds[i] = lay.max_bonds[i];
     if (h_core_offsets) h_core_offsets[i] = lay.core_off[i];
@@ -175,87 +177,135 @@ extern "C" int ndmps_tt_layout(int L, const int64_t* h_dims, int64_t max_bond, i
   return NDMPS_OK;
 }
 
-extern "C" int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cutoff,
-                                  int64_t max_bond, float* d_cores, const int64_t* h_core_offsets,
-                                  int64_t* h_bonds_out, double* h_spectra, const int64_t* h_spec_offsets,
-                                  void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
-  NDMPS_REQUIRE(d_dense && h_dims && d_cores && h_core_offsets && h_bonds_out, "NULL sweep argument");
+extern "C" int64_t ndmps_tt_sweep_batched_workspace_bytes(int batch, int L, const int64_t* h_dims,
+                                                          int64_t max_bond) {
+  SweepLayout lay;
+  if (!h_dims || sweep_layout(L, h_dims, max_bond, batch, lay) != NDMPS_OK) return -1;
+  return lay.workspace;
+}
+
+// All volumes of the batch have the same site dims; they advance through the sites in lockstep
+// so that every site's eigenproblems are solved by ONE batched Jacobi (its sequential depth is
+// the cost of the path); Gram / projection launches stay per volume (they fill the chip alone).
+extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const int64_t* h_dims,
+                                          double cutoff, int64_t max_bond, float* const* h_cores,
+                                          const int64_t* h_core_offsets, int64_t* h_bonds_out,
+                                          double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
+                                          int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(h_dense && h_dims && h_cores && h_core_offsets && h_bonds_out, "NULL sweep argument");
   NDMPS_REQUIRE(cutoff >= 0.0, "cutoff must be non-negative");
   SweepLayout lay;
-  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, lay));
+  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, batch, lay));
   if (d_ws == nullptr || ws_bytes < lay.workspace) {
     ndmps::set_error("sweep workspace too small: %lld < %lld", (long long)ws_bytes, (long long)lay.workspace);
     return NDMPS_EWORKSPACE;
   }
+  for (int b = 0; b < batch; ++b) NDMPS_REQUIRE(h_dense[b] && h_cores[b], "NULL volume or core arena %d", b);
   hipStream_t s = (hipStream_t)stream;
+  const int64_t sq = lay.small_max * lay.small_max;
   Arena ar(d_ws, ws_bytes);
-  float* other = ar.take<float>(lay.numel);
-  double* G = ar.take<double>(lay.small_max * lay.small_max);
-  double* V = ar.take<double>(lay.small_max * lay.small_max);
-  double* w = ar.take<double>(lay.small_max);
-  double* sig = ar.take<double>(lay.small_max);
-  const int64_t ev_ws_bytes = ndmps_syevj_workspace_bytes(lay.small_max);
+  float* other = ar.take<float>((int64_t)batch * lay.numel);
+  double* G = ar.take<double>((int64_t)batch * sq);
+  double* V = ar.take<double>((int64_t)batch * sq);
+  double* w = ar.take<double>((int64_t)batch * lay.small_max);
+  double* sig = ar.take<double>((int64_t)batch * lay.small_max);
+  const int64_t ev_ws_bytes = ndmps_syevj_batched_workspace_bytes(lay.small_max, batch);
   char* ev_ws = ar.take<char>(ev_ws_bytes);
   char* gram_ws = ar.take<char>(lay.gram_ws);
-  double* A64 = ar.take<double>(lay.wide_elems);
+  double* A64 = ar.take<double>((int64_t)batch * lay.wide_elems);
   double* UtA = ar.take<double>(lay.wide_elems);
   NDMPS_REQUIRE(other && G && V && w && sig && ev_ws && gram_ws && A64 && UtA, "workspace carve failed");
 
-  float* cur = d_dense;
-  float* nxt = other;
-  int64_t cur_elems = lay.numel;
-  int64_t chi_r = 1;
-  h_bonds_out[0] = 1;
-  h_bonds_out[L] = 1;
-  std::vector<double> host_w;
+  std::vector<float*> cur(batch), nxt(batch);
+  std::vector<int64_t> chi_r(batch, 1), cur_elems(batch, lay.numel), eig_n(batch), kept(batch);
+  for (int b = 0; b < batch; ++b) {
+    cur[b] = h_dense[b];
+    nxt[b] = other + (int64_t)b * lay.numel;
+    h_bonds_out[(int64_t)b * (L + 1)] = 1;
+    h_bonds_out[(int64_t)b * (L + 1) + L] = 1;
+  }
+  const int64_t spec_total = h_spec_offsets ? h_spec_offsets[L] : 0;
+  std::vector<double> host_w((size_t)batch * lay.small_max);
 
   for (int i = L - 1; i >= 1; --i) {
-    const int64_t n = h_dims[i] * chi_r;
-    const int64_t m = cur_elems / n;
-    const int64_t small = std::min(m, n);
-    float* core = d_cores + h_core_offsets[i];
+    // ---- small-side Gram matrices
+    int64_t m = 0;
+    for (int b = 0; b < batch; ++b) {
+      const int64_t n = h_dims[i] * chi_r[b];
+      m = cur_elems[b] / n;
+      eig_n[b] = std::min(m, n);
+      double* Gb = G + (int64_t)b * sq;
+      if (n <= m) {
+        const int64_t need = ndmps_gram_workspace_bytes(m, n);
+        NDMPS_REQUIRE(need <= lay.gram_ws, "internal: Gram workspace bound violated (%lld > %lld)",
+                      (long long)need, (long long)lay.gram_ws);
+        NDMPS_TRY(ndmps_gram_f32(cur[b], m, n, n, Gb, gram_ws, lay.gram_ws, s));
+      } else {
+        double* Ab = A64 + (int64_t)b * lay.wide_elems;
+        hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(m * n)), dim3(256), 0, s, cur[b], m * n, Ab);
+        NDMPS_LAUNCH_CHECK();
+        NDMPS_TRY(ndmps_dgemm(0, 1, m, m, n, Ab, n, Ab, n, Gb, m, s));
+      }
+    }
+    // ---- one batched eigen-solve for the site
     int sweeps = 0;
-    const bool tall = n <= m;
-    if (tall) {
-      NDMPS_TRY(ndmps_gram_f32(cur, m, n, n, G, gram_ws, lay.gram_ws, s));
-    } else {
-      hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(m * n)), dim3(256), 0, s, cur, m * n, A64);
-      NDMPS_LAUNCH_CHECK();
-      NDMPS_TRY(ndmps_dgemm(0, 1, m, m, n, A64, n, A64, n, G, m, s));
-    }
-    NDMPS_TRY(ndmps_syevj_f64(G, small, V, w, ev_ws, ev_ws_bytes, &sweeps, s));
-    host_w.resize(small);
-    NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, small * sizeof(double), hipMemcpyDeviceToHost, s));
+    NDMPS_TRY(ndmps_syevj_batched_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, ev_ws, ev_ws_bytes,
+                                      &sweeps, s));
+    NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
+                                   hipMemcpyDeviceToHost, s));
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-    for (auto& x : host_w) x = sqrt(std::max(x, 0.0));
-    const int64_t k = kept_rank(host_w, cutoff, max_bond);
-    if (h_spectra && h_spec_offsets)
-      memcpy(h_spectra + h_spec_offsets[i], host_w.data(), small * sizeof(double));
-
-    if (tall) {
-      hipLaunchKernelGGL(core_from_vectors_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, V, n, k, core);
-      NDMPS_LAUNCH_CHECK();
-      NDMPS_TRY(ndmps_sgemm(0, 1, m, k, n, cur, n, core, n, nxt, k, s));
-    } else {
-      hipLaunchKernelGGL(sqrt_clamp_kernel, dim3(grid1d(small)), dim3(256), 0, s, w, small, sig);
-      // carry = U_k diag(sigma_k)
-      hipLaunchKernelGGL(scale_cols_to_f32_kernel, dim3(grid1d(m * k)), dim3(256), 0, s, V, m, m, k, sig, 1.0, nxt);
-      NDMPS_LAUNCH_CHECK();
-      // core = diag(1/sigma_k) U_k^T A
-      NDMPS_TRY(ndmps_dgemm(1, 0, k, n, m, V, m, A64, n, UtA, n, s));
-      hipLaunchKernelGGL(scale_rows_to_f32_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, UtA, k, n, sig, -1.0, core);
-      NDMPS_LAUNCH_CHECK();
+    // ---- rank decision, core and carried matrix per volume
+    for (int b = 0; b < batch; ++b) {
+      const int64_t n = h_dims[i] * chi_r[b];
+      const int64_t small = eig_n[b];
+      std::vector<double> sv(host_w.begin() + (int64_t)b * lay.small_max,
+                             host_w.begin() + (int64_t)b * lay.small_max + small);
+      for (auto& x : sv) x = sqrt(std::max(x, 0.0));
+      const int64_t k = kept_rank(sv, cutoff, max_bond);
+      if (h_spectra && h_spec_offsets)
+        memcpy(h_spectra + (int64_t)b * spec_total + h_spec_offsets[i], sv.data(), small * sizeof(double));
+      float* core = h_cores[b] + h_core_offsets[i];
+      double* Vb = V + (int64_t)b * sq;
+      double* wb = w + (int64_t)b * lay.small_max;
+      double* sigb = sig + (int64_t)b * lay.small_max;
+      if (n <= m) {
+        hipLaunchKernelGGL(core_from_vectors_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, Vb, n, k, core);
+        NDMPS_LAUNCH_CHECK();
+        NDMPS_TRY(ndmps_sgemm(0, 1, m, k, n, cur[b], n, core, n, nxt[b], k, s));
+      } else {
+        double* Ab = A64 + (int64_t)b * lay.wide_elems;
+        hipLaunchKernelGGL(sqrt_clamp_kernel, dim3(grid1d(small)), dim3(256), 0, s, wb, small, sigb);
+        hipLaunchKernelGGL(scale_cols_to_f32_kernel, dim3(grid1d(m * k)), dim3(256), 0, s, Vb, m, m, k, sigb, 1.0,
+                           nxt[b]);  // carry = U_k diag(sigma_k)
+        NDMPS_LAUNCH_CHECK();
+        NDMPS_TRY(ndmps_dgemm(1, 0, k, n, m, Vb, m, Ab, n, UtA, n, s));
+        hipLaunchKernelGGL(scale_rows_to_f32_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, UtA, k, n, sigb, -1.0,
+                           core);  // core = diag(1/sigma_k) U_k^T A
+        NDMPS_LAUNCH_CHECK();
+      }
+      std::swap(cur[b], nxt[b]);
+      cur_elems[b] = m * k;
+      chi_r[b] = k;
+      h_bonds_out[(int64_t)b * (L + 1) + i] = k;
     }
-    std::swap(cur, nxt);
-    cur_elems = m * k;
-    chi_r = k;
-    h_bonds_out[i] = k;
   }
   // site 0 carries the norm: (1, d_0, chi_1)
-  NDMPS_CHECK_HIP(hipMemcpyAsync(d_cores + h_core_offsets[0], cur, cur_elems * sizeof(float),
-                                 hipMemcpyDeviceToDevice, s));
+  for (int b = 0; b < batch; ++b)
+    NDMPS_CHECK_HIP(hipMemcpyAsync(h_cores[b] + h_core_offsets[0], cur[b], cur_elems[b] * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   return NDMPS_OK;
+}
+
+extern "C" int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cutoff,
+                                  int64_t max_bond, float* d_cores, const int64_t* h_core_offsets,
+                                  int64_t* h_bonds_out, double* h_spectra, const int64_t* h_spec_offsets,
+                                  void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_dense && d_cores, "NULL sweep argument");
+  float* dense[1] = {d_dense};
+  float* cores[1] = {d_cores};
+  return ndmps_tt_sweep_batched_f32(1, dense, L, h_dims, cutoff, max_bond, cores, h_core_offsets, h_bonds_out,
+                                    h_spectra, h_spec_offsets, d_ws, ws_bytes, stream);
 }
 
 // =================================================================== bond truncation

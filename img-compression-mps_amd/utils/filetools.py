@@ -43,6 +43,24 @@ def minmax(t):
     return float(lo.value), float(hi.value)
 
 
+def minmax_many(tensors):
+    """[(min, max)] of several device fp32 tensors: one launch, one synchronisation."""
+    import torch
+
+    lib = _lib.load()
+    ts = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+    count = len(ts)
+    if count == 0:
+        return []
+    nbytes = lib.ndmps_minmax_many_workspace_bytes(count)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ts[0].device)
+    ptrs = (C.c_void_p * count)(*[t.data_ptr() for t in ts])
+    lens = _lib.i64_array([t.numel() for t in ts])
+    out = (C.c_float * (2 * count))()
+    _lib.check(lib.ndmps_minmax_many_f32(count, ptrs, lens, out, ws.data_ptr(), nbytes, _lib.stream_ptr()))
+    return [(float(out[2 * i]), float(out[2 * i + 1])) for i in range(count)]
+
+
 def scale_to_dtype(t, dtype=np.uint8):
     """Device tensor -> unsigned-int device tensor, (x - min) / max(x - min) * iinfo.max, truncated."""
     import torch

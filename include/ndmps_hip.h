@@ -92,6 +92,11 @@ int ndmps_sumsq_f32(const float* d_x, int64_t n, double* h_out, void* d_ws, int6
                     ndmps_stream_t stream);
 int ndmps_minmax_f32(const float* d_x, int64_t n, float* h_min, float* h_max, void* d_ws,
                      int64_t ws_bytes, ndmps_stream_t stream);
+/* min/max of `count` tensors with one launch and one synchronisation (boundary_list of all
+ * cores, core/ndmps.py:80-82): h_ptrs / h_lens are host arrays, h_out gets (min, max) pairs */
+int64_t ndmps_minmax_many_workspace_bytes(int count);
+int ndmps_minmax_many_f32(int count, const float* const* h_ptrs, const int64_t* h_lens,
+                          float* h_out, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
 int ndmps_scale_f32(float* d_x, int64_t n, double factor, ndmps_stream_t stream);
 int64_t ndmps_reduce_workspace_bytes(void);
 
@@ -116,11 +121,22 @@ int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* 
 int64_t ndmps_syevj_workspace_bytes(int64_t n);
 int ndmps_syevj_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
                     int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
+/* batch of independent eigenproblems solved in lockstep (one launch sequence for all):
+ * matrix b is d_G + b*stride_G, n_b x n_b (ld n_b); outputs likewise.  Same conventions. */
+int64_t ndmps_syevj_batched_workspace_bytes(int64_t n_max, int batch);
+int ndmps_syevj_batched_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n, double* d_V,
+                            int64_t stride_V, double* d_w, int64_t stride_w, void* d_ws,
+                            int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
 /* same contract, scalar-parallel Jacobi (one launch per rotation step); kept as the
  * cross-check of the block solver above */
 int64_t ndmps_syevj_simple_workspace_bytes(int64_t n);
 int ndmps_syevj_simple_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
                            int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
+
+/* diagnostic only: per-segment s_memtime sums of one stamped diag launch of the block
+ * Jacobi solver (see eig_block.hip); never called by the product path */
+int ndmps_debug_diag_stamps(double* d_Gp, int np, void* d_ws, int64_t ws_bytes,
+                            unsigned long long* h_out, int full, ndmps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * MPS sweep: replaces quimb MatrixProductState.from_dense (core/ndmps.py:74).
@@ -143,6 +159,18 @@ int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cuto
                        int64_t max_bond, float* d_cores, const int64_t* h_core_offsets,
                        int64_t* h_bonds_out, double* h_spectra, const int64_t* h_spec_offsets,
                        void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+
+/* Batch of independent volumes of the same shape (the reference loops over lists of tensors,
+ * evaluation/benchmark.py:73-76): h_dense[b] / h_cores[b] are per-volume device pointers,
+ * h_bonds_out is batch x (L+1), h_spectra batch x h_spec_offsets[L].  The volumes advance
+ * through the sites in lockstep so each site's eigenproblems are one batched solve. */
+int64_t ndmps_tt_sweep_batched_workspace_bytes(int batch, int L, const int64_t* h_dims,
+                                               int64_t max_bond);
+int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const int64_t* h_dims,
+                               double cutoff, int64_t max_bond, float* const* h_cores,
+                               const int64_t* h_core_offsets, int64_t* h_bonds_out,
+                               double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
+                               int64_t ws_bytes, ndmps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Bond truncation: replaces quimb tensor_compress_bond(t1, t2, cutoff, cutoff_mode="rel")

@@ -512,3 +512,58 @@ def test_torch_input_and_device_output_stay_on_gpu():
     o = NDMPS.from_tensor(x, max_bond=8)
     out = o.to_tensor(as_torch=True)
     assert out.is_cuda and out.shape == x.shape and torch.equal(x, keep)
+
+
+# ------------------------------------------------------------------------- batched (lockstep) path
+def test_batched_eigensolver_mixed_sizes():
+    lib = _lib.load()
+    sizes = [40, 7, 96, 33, 1]
+    nmax = max(sizes)
+    rng = np.random.default_rng(42)
+    mats = []
+    g_all = np.zeros((len(sizes), nmax * nmax))
+    for b, n in enumerate(sizes):
+        a = rng.standard_normal((n + 3, n)) * np.logspace(0, -4, n)[None, :]
+        g = a.T @ a
+        mats.append(g)
+        g_all[b, : n * n] = g.reshape(-1)
+    tg = dev(g_all)
+    tv = torch.zeros_like(tg)
+    tw = torch.zeros((len(sizes), nmax), dtype=torch.float64, device=DEV)
+    nbytes = lib.ndmps_syevj_batched_workspace_bytes(nmax, len(sizes))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    sweeps = C.c_int()
+    _lib.check(lib.ndmps_syevj_batched_f64(len(sizes), tg.data_ptr(), nmax * nmax, _lib.i64_array(sizes),
+                                           tv.data_ptr(), nmax * nmax, tw.data_ptr(), nmax, ws.data_ptr(), nbytes,
+                                           C.byref(sweeps), sp()))
+    for b, n in enumerate(sizes):
+        w = tw[b, :n].cpu().numpy()
+        v = tv[b, : n * n].cpu().numpy().reshape(n, n)
+        ref = np.linalg.eigvalsh(mats[b])[::-1]
+        assert np.abs(w - ref).max() <= 1e-13 * ref[0]
+        assert np.abs(v.T @ v - np.eye(n)).max() <= 1e-13
+        assert np.abs(mats[b] @ v - v * w[None, :]).max() <= 1e-13 * ref[0]
+
+
+def test_from_tensors_equals_from_tensor_one_by_one():
+    vols = [synthetic_mri((32, 32, 32), seed=s) for s in (1, 2, 3)]
+    vols[1] = vols[1] * 0.25  # different scales and spectra inside one batch
+    batched = NDMPS.from_tensors(vols, max_bond=12)
+    for v, ob in zip(vols, batched):
+        single = NDMPS.from_tensor(v, max_bond=12)
+        assert ob.bond_sizes() == single.bond_sizes()
+        assert np.array_equal(ob.to_tensor(), single.to_tensor())
+        assert ob.norm_value == single.norm_value
+        assert np.array_equal(ob.boundary_list, single.boundary_list)
+    exact = NDMPS.from_tensors(vols)  # cutoff-limited bonds may differ per volume
+    for v, ob in zip(vols, exact):
+        assert np.abs(ob.to_tensor() - v).max() <= 2e-5 * np.abs(v).max()
+    with pytest.raises(ValueError):
+        NDMPS.from_tensors([vols[0], np.zeros((4, 4), dtype=np.float32)])
+    assert NDMPS.from_tensors([]) == []
+
+
+def test_minmax_many_matches_single():
+    ts = [torch.randn(n, device=DEV) for n in (1, 17, 4096, 100003)]
+    got = hft.minmax_many(ts)
+    assert got == [hft.minmax(t) for t in ts]
