@@ -1,29 +1,31 @@
-// Block two-sided Jacobi eigen-solver (fp64), the production path of ndmps_syevj_f64.
+// Block two-sided Jacobi eigen-solver (fp64), the production path of ndmps_syevj_f64 and of the
+// batched sweep.
 //
-// The matrix (padded to a multiple of 32) is cut into 16-wide index blocks.  A sweep visits
-// every pair of blocks once (round-robin over blocks, nb-1 outer steps, nb/2 disjoint block
-// pairs per step).  Per outer step, two launches:
+// The matrix (padded to a multiple of 32) is cut into 16-wide index blocks.  A sweep visits every
+// pair of blocks once (round-robin over blocks: nb-1 outer steps, nb/2 disjoint block pairs per
+// step).  One launch per outer step, with two kinds of workgroups:
 //
-//   diag  : one workgroup per block pair (I, J) keeps the 32x32 diagonal sub-matrix of
-//           I u J in LDS, runs the Jacobi rotations of that visit on it (wave-parallel:
-//           16 disjoint rotations per inner step, 256 threads each owning one 2x2 block) and
-//           accumulates their product Q (32x32).  Outer step 0 of a sweep rotates ALL index
-//           pairs inside I u J (31 inner steps, covers the intra-block pairs once per sweep);
-//           later steps rotate only the 16x16 cross pairs (16 inner steps) -- every index pair
-//           of the matrix is rotated exactly once per sweep, as in the scalar cyclic method.
-//   apply : one workgroup per 32x32 tile: G_tile <- Q_A^T G_tile Q_B for every off-diagonal
-//           tile (A, B) of block pairs, V_strip <- V_strip Q_B; f64 MFMA (16x16x4), operands
-//           from LDS.  A tile is read and written by its own workgroup only, so the update
-//           is in place.
+//   apply (step t) : one workgroup per 32x32 tile of the block-pair tiling of step t:
+//           G_out[tile] = Q_A^T G_in[tile] Q_B (off-diagonal tiles), = the rotated diagonal tile
+//           prepared earlier (diagonal tiles), V[strip] <- V[strip] Q_B; f64 MFMA (16x16x4) from
+//           LDS.  G ping-pongs between two buffers, V is updated in place.
+//   diag (step t+1): one workgroup per block pair (I, J) of the NEXT step builds the 32x32 diagonal
+//           sub-matrix of I u J as it will be after step t -- its two 16x16 diagonal blocks come
+//           from the prepared diagonal tiles of step t, its cross block from Q_A^T G_in[tile] Q_B of
+//           the one tile that holds it -- and runs the Jacobi rotations of that visit on it in LDS
+//           (16 disjoint rotations per inner step, 256 threads each owning one 2x2 block, one
+//           barrier per inner step, S double-buffered), accumulating their product Q.  The first
+//           step of a sweep rotates ALL index pairs inside I u J (31 inner steps), later steps only
+//           the 16x16 cross pairs (16 inner steps): every index pair once per sweep.
+//
+// The two roles touch disjoint outputs, so the serial chain of a sweep is nb-1 launches whose
+// length is max(apply, diag) instead of 2 (nb-1) launches of apply + diag (n-1 = 511 launches for
+// the scalar-parallel method in eig.hip, kept as ndmps_syevj_simple_f64 for cross-checks).
 //
 // Batched: every kernel takes a batch of matrices (blockIdx.y); matrices of different size are
 // padded to the common np (padded indices never rotate) and converged ones are skipped, so B
-// eigenproblems cost the sequential depth of one.
-//
-// Sequential depth per sweep: 2 (nb-1) launches (62 for n = 512) instead of n-1 = 511 for
-// the scalar-parallel method in eig.hip (kept as ndmps_syevj_simple_f64 for cross-checks).
-// Before the first sweep the matrix is permuted so its diagonal is descending (faster
-// convergence on the graded Gram matrices of the sweep).
+// eigenproblems cost the sequential depth of one.  Before the first sweep each matrix is permuted
+// so that its diagonal is descending.
 #include <math.h>
 
 #include <algorithm>
@@ -47,16 +49,18 @@ struct BatchDesc {
   double* w_out;       // n eigenvalues, descending
   int n;
   int done;            // converged: later launches skip this matrix
-  int rotated;         // rotations above tol_conv in the current sweep
+  int rotated[2];      // rotations above tol_conv, per sweep parity
+  int final_buf;       // which G buffer holds the converged matrix
   int pad;
   double tol_conv;
   double tol_rot;
 };
 
-struct Work {          // common padded working set, strides per matrix
-  double* G;           // [B][np][np]
-  double* V;           // [B][np][np]
-  double* Q;           // [B][nb/2][PS][PS]
+struct Work {          // common padded working set; per-matrix strides np*np and (nb/2)*PS*PS
+  double* G[2];        // ping-pong
+  double* V;
+  double* Q[2];        // rotations of the step being applied / being prepared
+  double* D[2];        // rotated diagonal tiles, same parity scheme
   int* pos;            // [B][np]
   double* sign;        // [B][np]
   int np;
@@ -136,8 +140,10 @@ __global__ void __launch_bounds__(256) blk_scale_kernel(BatchDesc* __restrict__ 
   if (threadIdx.x == 0) {
     d.tol_conv = 1e-15 * red[0];
     d.tol_rot = 1e-19 * red[0];
-    d.rotated = 0;
+    d.rotated[0] = 0;
+    d.rotated[1] = 0;
     d.done = 0;
+    d.final_buf = 0;
   }
 }
 
@@ -157,11 +163,11 @@ __global__ void __launch_bounds__(256) blk_order_kernel(const BatchDesc* __restr
   w.pos[(int64_t)blockIdx.y * w.np + i] = rk;
 }
 
-// Gp = P^T sym(G) P (padded with zeros), Vp = P on the real indices, identity on the padding
+// G[0] = P^T sym(G) P (padded with zeros), V = P on the real indices, identity on the padding
 __global__ void __launch_bounds__(256) blk_init_kernel(const BatchDesc* __restrict__ desc, Work w) {
   const BatchDesc& d = desc[blockIdx.y];
   const int n = d.n, np = w.np;
-  double* Gp = w.G + (int64_t)blockIdx.y * np * np;
+  double* Gp = w.G[0] + (int64_t)blockIdx.y * np * np;
   double* Vp = w.V + (int64_t)blockIdx.y * np * np;
   const int64_t total = (int64_t)np * np;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(256) blk_scatter_kernel(const BatchDesc* __res
   const BatchDesc& d = desc[blockIdx.y];
   const double* G = d.G_in;
   const int n = d.n, np = w.np;
-  double* Gp = w.G + (int64_t)blockIdx.y * np * np;
+  double* Gp = w.G[0] + (int64_t)blockIdx.y * np * np;
   double* Vp = w.V + (int64_t)blockIdx.y * np * np;
   const int* pos = w.pos + (int64_t)blockIdx.y * np;
   const int64_t total = (int64_t)n * n;
@@ -185,173 +191,29 @@ __global__ void __launch_bounds__(256) blk_scatter_kernel(const BatchDesc* __res
   }
 }
 
-// between sweeps: a matrix whose last sweep rotated nothing above tol_conv is done
-__global__ void blk_check_kernel(BatchDesc* __restrict__ desc, int batch, int* __restrict__ remaining) {
+// after the launches of sweep `sweep`: a matrix whose sweep rotated nothing above tol_conv is done;
+// its converged G sits in buffer `buf_now`
+__global__ void blk_check_kernel(BatchDesc* __restrict__ desc, int batch, int sweep, int buf_now,
+                                 int* __restrict__ remaining) {
   __shared__ int left;
   if (threadIdx.x == 0) left = 0;
   __syncthreads();
   for (int b = threadIdx.x; b < batch; b += blockDim.x) {
     if (!desc[b].done) {
-      if (desc[b].rotated == 0) desc[b].done = 1;
-      else atomicAdd(&left, 1);
+      if (desc[b].rotated[sweep & 1] == 0) {
+        desc[b].done = 1;
+        desc[b].final_buf = buf_now;
+      } else {
+        atomicAdd(&left, 1);
+      }
     }
-    desc[b].rotated = 0;
+    desc[b].rotated[sweep & 1] = 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) *remaining = left;
 }
 
-// ---------------------------------------------------------------------------- diag phase
-// full != 0: all pairs inside the 32 indices (31 inner steps); else the 16x16 cross pairs.
-// solve != 0 (single block pair = whole matrix): repeat full sweeps in LDS until converged.
-//
-// One barrier per inner step: every lane computes the rotation of pair (lane & 15) itself
-// (it is its column rotation; the row rotation comes from lane K by a wave shuffle), and S is
-// double-buffered in LDS so a step reads only what the previous step wrote.
-template <bool STAMP>
-__global__ void __launch_bounds__(256)
-blk_diag_kernel(BatchDesc* __restrict__ desc, Work w, int outer_step, int full, int solve,
-                unsigned long long* __restrict__ stamps) {
-  BatchDesc& d = desc[blockIdx.y];
-  if (d.done) return;
-  const int np = w.np, nb = w.nb;
-  double* G = w.G + (int64_t)blockIdx.y * np * np;
-  double* Qbuf = w.Q + (int64_t)blockIdx.y * (nb / 2) * PS * PS;
-  // STAMP builds are diagnostic only (ndmps_debug_diag_stamps): per-segment s_memtime sums of
-  // wave 0 go to `stamps`, which nothing else reads.
-  unsigned long long t_rot = 0, t_app = 0, t_bar = 0, t_load = 0, t_store = 0, t0 = 0, t1 = 0;
-#define NDMPS_STAMP(var)                                                        \
-  if (STAMP) {                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                          \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                          \
-  }
-  NDMPS_STAMP(t0);
-  __shared__ double Sb[2][PS][LD];
-  __shared__ double Q[PS][LD];
-  __shared__ int cnt;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  int bi, bj;
-  circle_pair(blockIdx.x, outer_step, nb, bi, bj);
-  if (bi > bj) {
-    const int tmp = bi;
-    bi = bj;
-    bj = tmp;
-  }
-  const double tol_rot = d.tol_rot, tol_conv = d.tol_conv;
-  if (tid == 0) cnt = 0;
-  // load the 32x32 diagonal sub-matrix (symmetrised) and Q = I
-  for (int e = tid; e < PS * PS; e += 256) {
-    const int a = e / PS, b = e % PS;
-    const int64_t ga = (a < BS ? bi * BS + a : bj * BS + a - BS);
-    const int64_t gb = (b < BS ? bi * BS + b : bj * BS + b - BS);
-    Sb[0][a][b] = 0.5 * (G[ga * np + gb] + G[gb * np + ga]);
-    Q[a][b] = (a == b) ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  NDMPS_STAMP(t1);
-  t_load = t1 - t0;
-
-  const int K = tid >> 4, M = tid & 15;
-  const int n_inner = full ? PS - 1 : BS;
-  const int max_rounds = solve ? kMaxSweepsBlock : 1;
-  bool converged = false;
-  int cur = 0;
-  for (int round = 0; round < max_rounds; ++round) {
-    int before = 0;
-    if (solve) {
-      before = cnt;
-      __syncthreads();  // nobody may bump cnt for this round before everyone has read it
-    }
-    for (int st = 0; st < n_inner; ++st) {
-      NDMPS_STAMP(t0);
-      double (*S)[LD] = Sb[cur];
-      double (*Sn)[LD] = Sb[cur ^ 1];
-      int p, q, r, s_;
-      if (full) {
-        circle_pair(K, st, PS, p, q);
-        circle_pair(M, st, PS, r, s_);
-      } else {
-        p = K;
-        q = BS + ((K + st) & (BS - 1));
-        r = M;
-        s_ = BS + ((M + st) & (BS - 1));
-      }
-      // own (column) rotation: pair M
-      const double arr = S[r][r], ass = S[s_][s_], ars = S[r][s_];
-      double c2, s2, t2;
-      rotation64(arr, ass, ars, tol_rot, c2, s2, t2);
-      // row rotation of pair K lives in lane K of this wave (lane & 15 == K)
-      const double c1 = __shfl(c2, K, 64), s1 = __shfl(s2, K, 64);
-      if (tid < 64) {  // wave 0 counts the pairs still above the convergence threshold
-        const unsigned long long m = __ballot(lane < BS && fabs(ars) > tol_conv);
-        if (lane == 0) cnt += __popcll(m);
-      }
-      NDMPS_STAMP(t1);
-      t_rot += t1 - t0;
-      {
-        const double gpr = S[p][r], gps = S[p][s_], gqr = S[q][r], gqs = S[q][s_];
-        const double xpr = c2 * gpr - s2 * gps, xps = s2 * gpr + c2 * gps;
-        const double xqr = c2 * gqr - s2 * gqs, xqs = s2 * gqr + c2 * gqs;
-        double ypr = c1 * xpr - s1 * xqr, yps = c1 * xps - s1 * xqs;
-        double yqr = s1 * xpr + c1 * xqr, yqs = s1 * xps + c1 * xqs;
-        if (K == M && s2 != 0.0) {  // the rotated pair itself: off-diagonal annihilated exactly
-          yps = 0.0;
-          yqr = 0.0;
-        }
-        Sn[p][r] = ypr;
-        Sn[p][s_] = yps;
-        Sn[q][r] = yqr;
-        Sn[q][s_] = yqs;
-        // Q <- Q J: rows 2K, 2K+1 (static), columns (r, s_); own entries only, in place
-        const int r0 = 2 * K, r1 = 2 * K + 1;
-        const double q0r = Q[r0][r], q0s = Q[r0][s_], q1r = Q[r1][r], q1s = Q[r1][s_];
-        Q[r0][r] = c2 * q0r - s2 * q0s;
-        Q[r0][s_] = s2 * q0r + c2 * q0s;
-        Q[r1][r] = c2 * q1r - s2 * q1s;
-        Q[r1][s_] = s2 * q1r + c2 * q1s;
-      }
-      NDMPS_STAMP(t0);
-      t_app += t0 - t1;
-      __syncthreads();
-      NDMPS_STAMP(t1);
-      t_bar += t1 - t0;
-      cur ^= 1;
-    }
-    if (solve && cnt == before) {  // cnt is stable here: last write was before the barrier
-      converged = true;
-      break;
-    }
-  }
-
-  // write back the rotated diagonal tile and Q
-  NDMPS_STAMP(t0);
-  for (int e = tid; e < PS * PS; e += 256) {
-    const int a = e / PS, b = e % PS;
-    const int64_t ga = (a < BS ? bi * BS + a : bj * BS + a - BS);
-    const int64_t gb = (b < BS ? bi * BS + b : bj * BS + b - BS);
-    G[ga * np + gb] = Sb[cur][a][b];
-    Qbuf[(int64_t)blockIdx.x * PS * PS + e] = Q[a][b];
-  }
-  if (tid == 0) {
-    if (!solve && cnt > 0) atomicAdd(&d.rotated, cnt);
-    if (solve && !converged) atomicAdd(&d.rotated, 1);
-  }
-  if (STAMP) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    NDMPS_STAMP(t1);
-    t_store = t1 - t0;
-    if (tid == 0) {
-      unsigned long long* o = stamps + 8 * blockIdx.x;
-      o[0] = t_load; o[1] = t_rot; o[2] = 0; o[3] = t_app; o[4] = t_bar; o[5] = t_store;
-      o[6] = (unsigned long long)n_inner; o[7] = 0;
-    }
-  }
-#undef NDMPS_STAMP
-}
-
-// ---------------------------------------------------------------------------- apply phase
+// ---------------------------------------------------------------------------- step kernel
 // C(32x32) = op(A) * B in LDS, f64 MFMA; 4 waves, one 16x16 output tile each.
 // TRANS_A: A given as (k, i) (i.e. C = A^T B).
 template <bool TRANS_A>
@@ -370,69 +232,243 @@ __device__ __forceinline__ void lds_gemm32(const double (*A)[LD], const double (
   for (int r = 0; r < 4; ++r) Cout[i0 + lk + 4 * r][j0 + li] = acc[r];
 }
 
-// blockIdx.x < half*half : G tile (A, B); else V strip tile (R, B)
-__global__ void __launch_bounds__(256)
-blk_apply_kernel(const BatchDesc* __restrict__ desc, Work w, int outer_step) {
-  if (desc[blockIdx.y].done) return;
-  __shared__ double T[PS][LD];
-  __shared__ double QA[PS][LD];
-  __shared__ double QB[PS][LD];
-  __shared__ double X[PS][LD];
-  const int np = w.np, nb = w.nb;
-  double* G = w.G + (int64_t)blockIdx.y * np * np;
-  double* V = w.V + (int64_t)blockIdx.y * np * np;
-  const double* Qbuf = w.Q + (int64_t)blockIdx.y * (nb / 2) * PS * PS;
-  const int half = nb >> 1;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  int bid = blockIdx.x;
-  const bool is_g = bid < half * half;
-  int pa = 0, pb, strip = 0;
-  if (is_g) {
-    pa = bid / half;
-    pb = bid % half;
-    if (pa == pb) return;  // diagonal tiles are written by the diag phase
+// sorted blocks (lo < hi) of pair k at outer step t
+__device__ __forceinline__ void pair_blocks(int k, int t, int nb, int& lo, int& hi) {
+  int a, b;
+  circle_pair(k, t, nb, a, b);
+  lo = min(a, b);
+  hi = max(a, b);
+}
+
+// which pair of step t holds block x, and is x its low (0) or high (1) block
+__device__ __forceinline__ void locate_block(int x, int t, int nb, int& k, int& pos) {
+  const int m1 = nb - 1;
+  int partner;
+  if (x == nb - 1) {
+    k = 0;
+    partner = t;
+  } else if (x == t) {
+    k = 0;
+    partner = nb - 1;
   } else {
-    bid -= half * half;
-    strip = bid / half;
-    pb = bid % half;
-  }
-  int bi_b, bj_b;
-  circle_pair(pb, outer_step, nb, bi_b, bj_b);
-  if (bi_b > bj_b) {
-    const int tmp = bi_b;
-    bi_b = bj_b;
-    bj_b = tmp;
-  }
-  int bi_a = 0, bj_a = 0;
-  if (is_g) {
-    circle_pair(pa, outer_step, nb, bi_a, bj_a);
-    if (bi_a > bj_a) {
-      const int tmp = bi_a;
-      bi_a = bj_a;
-      bj_a = tmp;
+    const int kk = (x - t + m1) % m1;  // x = (t + kk) mod m1
+    if (kk <= (m1 - 1) / 2) {
+      k = kk;
+      partner = (t - kk + m1) % m1;
+    } else {
+      k = m1 - kk;  // x = (t - k) mod m1
+      partner = (t + k) % m1;
     }
   }
-  double* M = is_g ? G : V;
-  for (int e = tid; e < PS * PS; e += 256) {
-    const int a = e / PS, b = e % PS;
-    const int64_t gr = is_g ? (a < BS ? bi_a * BS + a : bj_a * BS + a - BS) : (int64_t)strip * PS + a;
-    const int64_t gc = (b < BS ? bi_b * BS + b : bj_b * BS + b - BS);
-    T[a][b] = M[gr * np + gc];
-    QB[a][b] = Qbuf[(int64_t)pb * PS * PS + e];
-    if (is_g) QA[a][b] = Qbuf[(int64_t)pa * PS * PS + e];
+  pos = x < partner ? 0 : 1;
+}
+
+__device__ __forceinline__ int64_t pair_index(int e, int lo, int hi) {  // e in [0, 32)
+  return e < BS ? (int64_t)lo * BS + e : (int64_t)hi * BS + e - BS;
+}
+
+// grid.x = n_diag (diag role, dispatched first) + n_apply (apply role); grid.y = batch.
+//   t        : outer step applied by the apply role (ignored when n_apply == 0)
+//   t_next   : outer step prepared by the diag role; full_next: rotate all pairs (first step of a
+//              sweep); sweep_next: its sweep (selects the rotation counter)
+//   first    : diag role reads the initial matrix directly (nothing to apply yet)
+//   solve    : single block pair = whole matrix, iterate to convergence in LDS
+//   in, out  : G ping-pong indices;  q_cur: parity of the Q / D buffers being applied
+__global__ void __launch_bounds__(256)
+blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_next, int full_next,
+                int sweep_next, int first, int solve, int in, int q_cur) {
+  BatchDesc& d = desc[blockIdx.y];
+  if (d.done) return;
+  // four 32x32 tiles of LDS, shared by both roles (33 KB -> 4 workgroups per CU):
+  //   apply: T, QA, QB, X.   diag: the same four while the sub-matrix is built, then
+  //   Q = QA's slot, S ping-pong = X's and QB's slots (all dead by then), T unused.
+  __shared__ double tiles[4][PS][LD];
+  __shared__ int cnt;
+  double (*T)[LD] = tiles[0];
+  double (*QA)[LD] = tiles[1];
+  double (*QB)[LD] = tiles[2];
+  double (*X)[LD] = tiles[3];
+  double (*Q)[LD] = tiles[1];
+  double (*S0)[LD] = tiles[3];
+  double (*S1)[LD] = tiles[2];
+
+  const int np = w.np, nb = w.nb, half = nb >> 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t mat = (int64_t)blockIdx.y * np * np;
+  const int64_t qoff = (int64_t)blockIdx.y * half * PS * PS;
+  const double* Gin = w.G[in] + mat;
+  const double* Qcur = w.Q[q_cur] + qoff;
+  const double* Dcur = w.D[q_cur] + qoff;
+
+  if ((int)blockIdx.x >= n_diag) {
+    // ================================================================== apply role (step t)
+    double* Gout = w.G[in ^ 1] + mat;
+    double* V = w.V + mat;
+    int bid = blockIdx.x - n_diag;
+    const bool is_g = bid < half * half;
+    int pa = 0, pb, strip = 0;
+    if (is_g) {
+      pa = bid / half;
+      pb = bid % half;
+    } else {
+      bid -= half * half;
+      strip = bid / half;
+      pb = bid % half;
+    }
+    int lo_b, hi_b, lo_a = 0, hi_a = 0;
+    pair_blocks(pb, t, nb, lo_b, hi_b);
+    if (is_g) pair_blocks(pa, t, nb, lo_a, hi_a);
+    if (is_g && pa == pb) {  // diagonal tile: prepared (already rotated) by the diag role
+      for (int e = tid; e < PS * PS; e += 256) {
+        const int a = e / PS, b = e % PS;
+        Gout[pair_index(a, lo_a, hi_a) * np + pair_index(b, lo_b, hi_b)] = Dcur[(int64_t)pa * PS * PS + e];
+      }
+      return;
+    }
+    for (int e = tid; e < PS * PS; e += 256) {
+      const int a = e / PS, b = e % PS;
+      const int64_t gr = is_g ? pair_index(a, lo_a, hi_a) : (int64_t)strip * PS + a;
+      const int64_t gc = pair_index(b, lo_b, hi_b);
+      T[a][b] = is_g ? Gin[gr * np + gc] : V[gr * np + gc];
+      QB[a][b] = Qcur[(int64_t)pb * PS * PS + e];
+      if (is_g) QA[a][b] = Qcur[(int64_t)pa * PS * PS + e];
+    }
+    __syncthreads();
+    lds_gemm32<false>(T, QB, X, wave, lane);  // X = T Q_B
+    __syncthreads();
+    if (is_g) {
+      lds_gemm32<true>(QA, X, T, wave, lane);  // T = Q_A^T X
+      __syncthreads();
+    }
+    for (int e = tid; e < PS * PS; e += 256) {
+      const int a = e / PS, b = e % PS;
+      const int64_t gr = is_g ? pair_index(a, lo_a, hi_a) : (int64_t)strip * PS + a;
+      const int64_t gc = pair_index(b, lo_b, hi_b);
+      if (is_g) Gout[gr * np + gc] = T[a][b];
+      else V[gr * np + gc] = X[a][b];
+    }
+    return;
   }
-  __syncthreads();
-  lds_gemm32<false>(T, QB, X, wave, lane);  // X = T Q_B
-  __syncthreads();
-  if (is_g) {
-    lds_gemm32<true>(QA, X, T, wave, lane);  // T = Q_A^T X
+
+  // ==================================================================== diag role (step t_next)
+  double* Qnext = w.Q[q_cur ^ 1] + qoff;
+  double* Dnext = w.D[q_cur ^ 1] + qoff;
+  int lo, hi;
+  pair_blocks(blockIdx.x, t_next, nb, lo, hi);
+  const double tol_rot = d.tol_rot, tol_conv = d.tol_conv;
+  if (tid == 0) cnt = 0;
+  if (first) {
+    for (int e = tid; e < PS * PS; e += 256) {
+      const int a = e / PS, b = e % PS;
+      const int64_t ga = pair_index(a, lo, hi), gb = pair_index(b, lo, hi);
+      S0[a][b] = 0.5 * (Gin[ga * np + gb] + Gin[gb * np + ga]);
+      Q[a][b] = (a == b) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+  } else {
+    // the 32x32 sub-matrix of (lo, hi) as step t leaves it
+    int ka, pa, kb, pb;
+    locate_block(lo, t, nb, ka, pa);
+    locate_block(hi, t, nb, kb, pb);  // ka != kb: a block pair meets once per sweep
+    int a_lo, a_hi, b_lo, b_hi;
+    pair_blocks(ka, t, nb, a_lo, a_hi);
+    pair_blocks(kb, t, nb, b_lo, b_hi);
+    const int r16 = tid >> 4, c16 = tid & 15;  // one element of every 16 x 16 block per thread
+    // diagonal 16x16 blocks from the prepared diagonal tiles of step t (kept in registers
+    // until the LDS slots they go to are free)
+    const double d_lo = Dcur[(int64_t)ka * PS * PS + (pa * BS + r16) * PS + pa * BS + c16];
+    const double d_hi = Dcur[(int64_t)kb * PS * PS + (pb * BS + r16) * PS + pb * BS + c16];
+    for (int e = tid; e < PS * PS; e += 256) {
+      const int a = e / PS, b = e % PS;
+      T[a][b] = Gin[pair_index(a, a_lo, a_hi) * np + pair_index(b, b_lo, b_hi)];
+      QA[a][b] = Qcur[(int64_t)ka * PS * PS + e];
+      QB[a][b] = Qcur[(int64_t)kb * PS * PS + e];
+    }
+    __syncthreads();
+    lds_gemm32<false>(T, QB, X, wave, lane);  // X = T Q_B
+    __syncthreads();
+    lds_gemm32<true>(QA, X, T, wave, lane);  // T = Q_A^T X  (tile (ka, kb) after step t)
+    __syncthreads();
+    {
+      const double v = T[pa * BS + r16][pb * BS + c16];  // cross block (lo, hi)
+      S0[r16][BS + c16] = v;
+      S0[BS + c16][r16] = v;
+      S0[r16][c16] = d_lo;
+      S0[BS + r16][BS + c16] = d_hi;
+    }
+    for (int e = tid; e < PS * PS; e += 256) Q[e / PS][e % PS] = (e / PS == e % PS) ? 1.0 : 0.0;
     __syncthreads();
   }
+
+  const int K = tid >> 4, M = tid & 15;
+  const int n_inner = full_next ? PS - 1 : BS;
+  const int max_rounds = solve ? kMaxSweepsBlock : 1;
+  bool converged = false;
+  int cur = 0;
+  for (int round = 0; round < max_rounds; ++round) {
+    int before = 0;
+    if (solve) {
+      before = cnt;
+      __syncthreads();  // nobody may bump cnt for this round before everyone has read it
+    }
+    for (int st = 0; st < n_inner; ++st) {
+      double (*S)[LD] = cur ? S1 : S0;
+      double (*Sn)[LD] = cur ? S0 : S1;
+      int p, q, r, s_;
+      if (full_next) {
+        circle_pair(K, st, PS, p, q);
+        circle_pair(M, st, PS, r, s_);
+      } else {
+        p = K;
+        q = BS + ((K + st) & (BS - 1));
+        r = M;
+        s_ = BS + ((M + st) & (BS - 1));
+      }
+      // own (column) rotation: pair M; the row rotation of pair K lives in lane K of this wave
+      const double arr = S[r][r], ass = S[s_][s_], ars = S[r][s_];
+      double c2, s2, t2;
+      rotation64(arr, ass, ars, tol_rot, c2, s2, t2);
+      const double c1 = __shfl(c2, K, 64), s1 = __shfl(s2, K, 64);
+      if (tid < 64) {  // wave 0 counts the pairs still above the convergence threshold
+        const unsigned long long m = __ballot(lane < BS && fabs(ars) > tol_conv);
+        if (lane == 0) cnt += __popcll(m);
+      }
+      const double gpr = S[p][r], gps = S[p][s_], gqr = S[q][r], gqs = S[q][s_];
+      const double xpr = c2 * gpr - s2 * gps, xps = s2 * gpr + c2 * gps;
+      const double xqr = c2 * gqr - s2 * gqs, xqs = s2 * gqr + c2 * gqs;
+      double ypr = c1 * xpr - s1 * xqr, yps = c1 * xps - s1 * xqs;
+      double yqr = s1 * xpr + c1 * xqr, yqs = s1 * xps + c1 * xqs;
+      if (K == M && s2 != 0.0) {  // the rotated pair itself: off-diagonal annihilated exactly
+        yps = 0.0;
+        yqr = 0.0;
+      }
+      Sn[p][r] = ypr;
+      Sn[p][s_] = yps;
+      Sn[q][r] = yqr;
+      Sn[q][s_] = yqs;
+      // Q <- Q J: rows 2K, 2K+1 (static), columns (r, s_); own entries only, in place
+      const int r0 = 2 * K, r1 = 2 * K + 1;
+      const double q0r = Q[r0][r], q0s = Q[r0][s_], q1r = Q[r1][r], q1s = Q[r1][s_];
+      Q[r0][r] = c2 * q0r - s2 * q0s;
+      Q[r0][s_] = s2 * q0r + c2 * q0s;
+      Q[r1][r] = c2 * q1r - s2 * q1s;
+      Q[r1][s_] = s2 * q1r + c2 * q1s;
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (solve && cnt == before) {  // cnt is stable here: last write was before the barrier
+      converged = true;
+      break;
+    }
+  }
+
   for (int e = tid; e < PS * PS; e += 256) {
-    const int a = e / PS, b = e % PS;
-    const int64_t gr = is_g ? (a < BS ? bi_a * BS + a : bj_a * BS + a - BS) : (int64_t)strip * PS + a;
-    const int64_t gc = (b < BS ? bi_b * BS + b : bj_b * BS + b - BS);
-    M[gr * np + gc] = is_g ? T[a][b] : X[a][b];
+    Dnext[(int64_t)blockIdx.x * PS * PS + e] = (cur ? S1 : S0)[e / PS][e % PS];
+    Qnext[(int64_t)blockIdx.x * PS * PS + e] = Q[e / PS][e % PS];
+  }
+  if (tid == 0) {
+    if (!solve && cnt > 0) atomicAdd(&d.rotated[sweep_next & 1], cnt);
+    if (solve && !converged) atomicAdd(&d.rotated[sweep_next & 1], 1);
   }
 }
 
@@ -440,7 +476,7 @@ blk_apply_kernel(const BatchDesc* __restrict__ desc, Work w, int outer_step) {
 __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restrict__ desc, Work w) {
   const BatchDesc& d = desc[blockIdx.y];
   const int n = d.n, np = w.np;
-  const double* G = w.G + (int64_t)blockIdx.y * np * np;
+  const double* G = w.G[d.final_buf] + (int64_t)blockIdx.y * np * np;
   const double* V = w.V + (int64_t)blockIdx.y * np * np;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -479,7 +515,7 @@ __global__ void __launch_bounds__(256) blk_gather_kernel(const BatchDesc* __rest
 
 struct BlockLayout {
   int64_t np, nb;
-  int64_t off_g, off_v, off_q, off_desc, off_pos, off_sign, off_flag, off_stamp, total;
+  int64_t off_g[2], off_v, off_q[2], off_d[2], off_desc, off_pos, off_sign, off_flag, total;
 };
 
 BlockLayout block_layout(int64_t n_max, int64_t batch) {
@@ -492,14 +528,18 @@ BlockLayout block_layout(int64_t n_max, int64_t batch) {
     used = off + bytes;
     return off;
   };
-  l.off_g = take(batch * l.np * l.np * 8);
+  const int64_t qbytes = batch * (l.nb / 2) * PS * PS * 8;
+  l.off_g[0] = take(batch * l.np * l.np * 8);
+  l.off_g[1] = take(batch * l.np * l.np * 8);
   l.off_v = take(batch * l.np * l.np * 8);
-  l.off_q = take(batch * (l.nb / 2) * PS * PS * 8);
+  l.off_q[0] = take(qbytes);
+  l.off_q[1] = take(qbytes);
+  l.off_d[0] = take(qbytes);
+  l.off_d[1] = take(qbytes);
   l.off_desc = take(batch * (int64_t)sizeof(BatchDesc));
   l.off_pos = take(batch * l.np * 4);
   l.off_sign = take(batch * l.np * 8);
   l.off_flag = take(256);
-  l.off_stamp = take((l.nb / 2) * 64);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -513,9 +553,12 @@ int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, v
   }
   char* base = (char*)d_ws;
   Work w;
-  w.G = (double*)(base + l.off_g);
+  for (int i = 0; i < 2; ++i) {
+    w.G[i] = (double*)(base + l.off_g[i]);
+    w.Q[i] = (double*)(base + l.off_q[i]);
+    w.D[i] = (double*)(base + l.off_d[i]);
+  }
   w.V = (double*)(base + l.off_v);
-  w.Q = (double*)(base + l.off_q);
   w.pos = (int*)(base + l.off_pos);
   w.sign = (double*)(base + l.off_sign);
   w.np = (int)l.np;
@@ -534,24 +577,29 @@ int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, v
   NDMPS_LAUNCH_CHECK();
 
   int sweeps = 0, remaining = 1;
-  const int apply_grid = half * half + (np / PS) * half;
+  const int n_apply = half * half + (np / PS) * half;
+  const int steps = nb - 1;  // outer steps per sweep
   if (nb == 2) {
-    // every matrix is one block pair: solved in LDS by a single launch
-    hipLaunchKernelGGL(blk_diag_kernel<false>, dim3(1, B), dim3(256), 0, s, desc, w, 0, 1, 1, nullptr);
-    hipLaunchKernelGGL(blk_apply_kernel, dim3(apply_grid, B), dim3(256), 0, s, desc, w, 0);
-    hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, flag);
+    // every matrix is one block pair: solved in LDS by the diag role, then applied once
+    hipLaunchKernelGGL(blk_step_kernel, dim3(half, B), dim3(256), 0, s, desc, w, half, 0, 0, 1, 0, 1, 1, 0, 1);
+    hipLaunchKernelGGL(blk_step_kernel, dim3(n_apply, B), dim3(256), 0, s, desc, w, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, 0, 1, flag);
     NDMPS_LAUNCH_CHECK();
     sweeps = 1;
     NDMPS_CHECK_HIP(hipMemcpyAsync(&remaining, flag, sizeof(int), hipMemcpyDeviceToHost, s));
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   } else {
+    // prepare step 0 of sweep 0 from the initial matrix (diag role only; writes Q[0], D[0])
+    hipLaunchKernelGGL(blk_step_kernel, dim3(half, B), dim3(256), 0, s, desc, w, half, 0, 0, 1, 0, 1, 0, 0, 1);
+    int g = 0;  // global step counter: G buffer in = g & 1, Q/D parity of the step applied = g & 1
     while (sweeps < kMaxSweepsBlock) {
-      for (int step = 0; step < nb - 1; ++step) {
-        hipLaunchKernelGGL(blk_diag_kernel<false>, dim3(half, B), dim3(256), 0, s, desc, w, step,
-                           step == 0 ? 1 : 0, 0, nullptr);
-        hipLaunchKernelGGL(blk_apply_kernel, dim3(apply_grid, B), dim3(256), 0, s, desc, w, step);
+      for (int t = 0; t < steps; ++t, ++g) {
+        const int t_next = (t + 1) % steps;
+        const int sweep_next = sweeps + (t == steps - 1 ? 1 : 0);
+        hipLaunchKernelGGL(blk_step_kernel, dim3(half + n_apply, B), dim3(256), 0, s, desc, w, half, t, t_next,
+                           t_next == 0 ? 1 : 0, sweep_next, 0, 0, g & 1, g & 1);
       }
-      hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, flag);
+      hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, sweeps, g & 1, flag);
       NDMPS_LAUNCH_CHECK();
       ++sweeps;
       NDMPS_CHECK_HIP(hipMemcpyAsync(&remaining, flag, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -607,37 +655,4 @@ extern "C" int ndmps_syevj_f64(double* d_G, int64_t n, double* d_V, double* d_w,
                                int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream) {
   NDMPS_REQUIRE(n >= 1, "eigen size n=%lld must be positive", (long long)n);
   return ndmps_syevj_batched_f64(1, d_G, n * n, &n, d_V, n * n, d_w, n, d_ws, ws_bytes, h_sweeps, stream);
-}
-
-// Diagnostic (not used by the product path): run ONE diag launch of the stamped build on a padded
-// np x np matrix already on the device and return wave-0 s_memtime sums per workgroup:
-// [load, rotation, 0, apply, barrier, store, inner_steps, 0] x (np/32).
-extern "C" int ndmps_debug_diag_stamps(double* d_Gp, int np, void* d_ws, int64_t ws_bytes,
-                                       unsigned long long* h_out, int full, ndmps_stream_t stream) {
-  NDMPS_REQUIRE(d_Gp && d_ws && h_out && np >= 64 && np % PS == 0, "bad debug argument");
-  const BlockLayout l = block_layout(np, 1);
-  if (ws_bytes < l.total) return NDMPS_EWORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
-  char* base = (char*)d_ws;
-  Work w;
-  w.G = d_Gp;  // rotate the caller's matrix in place
-  w.V = (double*)(base + l.off_v);
-  w.Q = (double*)(base + l.off_q);
-  w.pos = (int*)(base + l.off_pos);
-  w.sign = (double*)(base + l.off_sign);
-  w.np = np;
-  w.nb = np / BS;
-  BatchDesc hd;
-  memset(&hd, 0, sizeof(hd));
-  hd.G_in = d_Gp;
-  hd.n = np;
-  BatchDesc* desc = (BatchDesc*)(base + l.off_desc);
-  unsigned long long* st = (unsigned long long*)(base + l.off_stamp);
-  NDMPS_CHECK_HIP(hipMemcpyAsync(desc, &hd, sizeof(hd), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(blk_scale_kernel, dim3(1, 1), dim3(256), 0, s, desc);
-  hipLaunchKernelGGL(blk_diag_kernel<true>, dim3(w.nb / 2, 1), dim3(256), 0, s, desc, w, full ? 0 : 1, full ? 1 : 0, 0, st);
-  NDMPS_LAUNCH_CHECK();
-  NDMPS_CHECK_HIP(hipMemcpyAsync(h_out, st, (size_t)(w.nb / 2) * 64, hipMemcpyDeviceToHost, s));
-  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-  return NDMPS_OK;
 }

@@ -133,11 +133,6 @@ int64_t ndmps_syevj_simple_workspace_bytes(int64_t n);
 int ndmps_syevj_simple_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
                            int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
 
-/* diagnostic only: per-segment s_memtime sums of one stamped diag launch of the block
- * Jacobi solver (see eig_block.hip); never called by the product path */
-int ndmps_debug_diag_stamps(double* d_Gp, int np, void* d_ws, int64_t ws_bytes,
-                            unsigned long long* h_out, int full, ndmps_stream_t stream);
-
 /* ---------------------------------------------------------------------------------
  * MPS sweep: replaces quimb MatrixProductState.from_dense (core/ndmps.py:74).
  * Right->left, per site: unfold (prod_{j<i} d_j) x (d_i chi_{i+1}) -> SVD (Gram + Jacobi,
