@@ -7,10 +7,12 @@ applied in the sweep, then NDMPS.to_tensor) on a synthetic 256^3 fp32 volume at 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU; every rank compresses and reconstructs its own volume (independent
-volumes shard with no data-path collective) -> weak scaling.  Rank 0 prints one
-JSON line.  At N=1 it also carries the CPU baseline (the NumPy oracle on the same volume, timed
-on the host cores) and the SSIM gap between the GPU and the oracle reconstruction.
+One process per GPU; a step is one batch of --batch independent volumes per GPU (encoded in
+lockstep by NDMPS.from_tensors, reconstructed one by one); independent volumes shard with no
+data-path collective -> weak scaling.  Rank 0 prints one JSON line; `single_volume`
+in it is the latency of a batch of one.  At N=1 it also carries the CPU baseline (the NumPy
+oracle on one volume of the batch, timed on the host cores) and the SSIM gap between the GPU and
+the oracle reconstruction of that volume.
 """
 import argparse
 import json
@@ -37,6 +39,9 @@ def parse():
     ap.add_argument("--mode", default="Std", choices=["Std", "DCT"])
     ap.add_argument("--batch", type=int, default=8, help="independent volumes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo + --share-gpu rehearses N ranks on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -56,10 +61,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     _lib.load()
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     from oracle.metrics import compute_ssim_by_dim, synthetic_mri  # data generator + checker only
 
@@ -98,7 +108,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ndmps_mod.set_stage_timer(None)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -129,7 +139,10 @@ def main():
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
-        "traffic": None,
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE 66 019 KB + WRITE_SIZE 65 536 KB,
+        # profiles/r01_c_pmc_*.txt; this kernel's 4-B/lane sorted gather is tallied exactly, checked
+        # against its known 64 MiB read); only valid for the default 256^3 volume
+        "traffic": (66019 + 65536) * 1024.0 if args.size == 256 else None,
         "read_frac": (4 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
         "end_to_end_algorithmic_GBps": args.batch * algo_bytes / (ms_per_step * 1e-3) / 1e9,
     }
