@@ -278,11 +278,15 @@ class NDMPS:
                 obj.sweep_spectra = spec_list
                 objs.append(obj)
             with _span("state"):
+                # boundary_list (ndmps.py:75) and norm_value (ndmps.py:76) of every volume from one
+                # launch.  The sweep leaves sites 1..L-1 right-isometric (rows of V^T), so
+                # mps @ mps = ||site 0||_F^2 up to the fp32 rounding of those rows (~1e-7 relative);
+                # update_norm() evaluates the full overlap contraction like the reference.
                 all_cores = [c for o in objs for c in o.mps.cores]
-                mm = _ft.minmax_many(all_cores)
+                mm, ss = _ft.minmax_many(all_cores, with_sumsq=True)
                 for b, o in enumerate(objs):
                     o.boundary_list = np.array([list(v) for v in mm[b * L:(b + 1) * L]])
-                    o.update_norm()
+                    o.norm_value = np.sqrt(ss[b * L])
         return objs
 
     # ----------------------------------------------------------------- bookkeeping

@@ -41,6 +41,7 @@ constexpr int BS = 16;       // block size
 constexpr int PS = 2 * BS;   // pair size (LDS sub-problem edge)
 constexpr int LD = PS + 1;   // padded LDS row
 constexpr int kMaxSweepsBlock = 40;
+constexpr int kTilesPerWg = 4;  // column pairs streamed by one apply workgroup
 
 // one entry per matrix of the batch (device array); blockIdx.y selects it in every kernel
 struct BatchDesc {
@@ -302,50 +303,73 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
 
   if ((int)blockIdx.x >= n_diag) {
     // ================================================================== apply role (step t)
+    // One workgroup = one row pair (or one 32-row strip of V) x kTilesPerWg column pairs: Q_A is
+    // loaded once, tiles stream through LDS; 16-byte global accesses (thread = row, 2-double segment).
     double* Gout = w.G[in ^ 1] + mat;
     double* V = w.V + mat;
+    const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
     int bid = blockIdx.x - n_diag;
-    const bool is_g = bid < half * half;
-    int pa = 0, pb, strip = 0;
+    const bool is_g = bid < half * chunks;
+    int pa = 0, strip = 0, chunk;
     if (is_g) {
-      pa = bid / half;
-      pb = bid % half;
+      pa = bid / chunks;
+      chunk = bid % chunks;
     } else {
-      bid -= half * half;
-      strip = bid / half;
-      pb = bid % half;
+      bid -= half * chunks;
+      strip = bid / chunks;
+      chunk = bid % chunks;
     }
-    int lo_b, hi_b, lo_a = 0, hi_a = 0;
-    pair_blocks(pb, t, nb, lo_b, hi_b);
+    int lo_a = 0, hi_a = 0;
     if (is_g) pair_blocks(pa, t, nb, lo_a, hi_a);
-    if (is_g && pa == pb) {  // diagonal tile: prepared (already rotated) by the diag role
-      for (int e = tid; e < PS * PS; e += 256) {
-        const int a = e / PS, b = e % PS;
-        Gout[pair_index(a, lo_a, hi_a) * np + pair_index(b, lo_b, hi_b)] = Dcur[(int64_t)pa * PS * PS + e];
-      }
-      return;
-    }
-    for (int e = tid; e < PS * PS; e += 256) {
-      const int a = e / PS, b = e % PS;
-      const int64_t gr = is_g ? pair_index(a, lo_a, hi_a) : (int64_t)strip * PS + a;
-      const int64_t gc = pair_index(b, lo_b, hi_b);
-      T[a][b] = is_g ? Gin[gr * np + gc] : V[gr * np + gc];
-      QB[a][b] = Qcur[(int64_t)pb * PS * PS + e];
-      if (is_g) QA[a][b] = Qcur[(int64_t)pa * PS * PS + e];
-    }
-    __syncthreads();
-    lds_gemm32<false>(T, QB, X, wave, lane);  // X = T Q_B
-    __syncthreads();
+    const int row = tid >> 3, c0 = (tid & 7) * 2;  // this thread's row and column offset inside a 16-block
+    const int64_t grow = is_g ? pair_index(row, lo_a, hi_a) : (int64_t)strip * PS + row;
+    const double* Min = is_g ? Gin : V;
+    double* Mout = is_g ? Gout : V;
     if (is_g) {
-      lds_gemm32<true>(QA, X, T, wave, lane);  // T = Q_A^T X
-      __syncthreads();
+      const double2 a0 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pa * PS * PS + row * PS + c0);
+      const double2 a1 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pa * PS * PS + row * PS + BS + c0);
+      QA[row][c0] = a0.x;
+      QA[row][c0 + 1] = a0.y;
+      QA[row][BS + c0] = a1.x;
+      QA[row][BS + c0 + 1] = a1.y;
     }
-    for (int e = tid; e < PS * PS; e += 256) {
-      const int a = e / PS, b = e % PS;
-      const int64_t gr = is_g ? pair_index(a, lo_a, hi_a) : (int64_t)strip * PS + a;
-      const int64_t gc = pair_index(b, lo_b, hi_b);
-      if (is_g) Gout[gr * np + gc] = T[a][b];
-      else V[gr * np + gc] = X[a][b];
+    for (int j = 0; j < kTilesPerWg; ++j) {
+      const int pb = chunk * kTilesPerWg + j;
+      if (pb >= half) break;
+      int lo_b, hi_b;
+      pair_blocks(pb, t, nb, lo_b, hi_b);
+      double* o0 = Mout + grow * np + (int64_t)lo_b * BS + c0;
+      double* o1 = Mout + grow * np + (int64_t)hi_b * BS + c0;
+      if (is_g && pa == pb) {  // diagonal tile: prepared (already rotated) by the diag role
+        const double* dsrc = Dcur + (int64_t)pa * PS * PS + row * PS;
+        *reinterpret_cast<double2*>(o0) = *reinterpret_cast<const double2*>(dsrc + c0);
+        *reinterpret_cast<double2*>(o1) = *reinterpret_cast<const double2*>(dsrc + BS + c0);
+        continue;
+      }
+      const double2 t0 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)lo_b * BS + c0);
+      const double2 t1 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)hi_b * BS + c0);
+      const double2 q0 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb * PS * PS + row * PS + c0);
+      const double2 q1 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb * PS * PS + row * PS + BS + c0);
+      __syncthreads();  // the previous tile's readers of T / QB / X are done
+      T[row][c0] = t0.x;
+      T[row][c0 + 1] = t0.y;
+      T[row][BS + c0] = t1.x;
+      T[row][BS + c0 + 1] = t1.y;
+      QB[row][c0] = q0.x;
+      QB[row][c0 + 1] = q0.y;
+      QB[row][BS + c0] = q1.x;
+      QB[row][BS + c0 + 1] = q1.y;
+      __syncthreads();
+      lds_gemm32<false>(T, QB, X, wave, lane);  // X = T Q_B
+      __syncthreads();
+      double (*res)[LD] = X;
+      if (is_g) {
+        lds_gemm32<true>(QA, X, T, wave, lane);  // T = Q_A^T X
+        __syncthreads();
+        res = T;
+      }
+      *reinterpret_cast<double2*>(o0) = make_double2(res[row][c0], res[row][c0 + 1]);
+      *reinterpret_cast<double2*>(o1) = make_double2(res[row][BS + c0], res[row][BS + c0 + 1]);
     }
     return;
   }
@@ -577,7 +601,8 @@ int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, v
   NDMPS_LAUNCH_CHECK();
 
   int sweeps = 0, remaining = 1;
-  const int n_apply = half * half + (np / PS) * half;
+  const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
+  const int n_apply = half * chunks + (np / PS) * chunks;
   const int steps = nb - 1;  // outer steps per sweep
   if (nb == 2) {
     // every matrix is one block pair: solved in LDS by the diag role, then applied once

@@ -105,31 +105,38 @@ __global__ void __launch_bounds__(256) minmax_final_kernel(const float* __restri
   }
 }
 
-// many small tensors at once: blockIdx.y = tensor, blockIdx.x = slice; partial (min, max) per slice
+// many small tensors at once: blockIdx.y = tensor, blockIdx.x = slice; partial (min, max, sum of
+// squares in fp64) per slice, as three doubles
 __global__ void __launch_bounds__(256)
 minmax_many_kernel(const float* const* __restrict__ ptrs, const int64_t* __restrict__ lens,
-                   float* __restrict__ partial) {
+                   double* __restrict__ partial) {
   __shared__ float rmin[4], rmax[4];
+  __shared__ double rsum[4];
   const float* x = ptrs[blockIdx.y];
   const int64_t n = lens[blockIdx.y];
   float lo = FLT_MAX, hi = -FLT_MAX;
+  double ss = 0.0;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const float v = x[i];
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
+    ss += (double)v * (double)v;
   }
   lo = wave_min(lo);
   hi = wave_max(hi);
+  ss = wave_sum(ss);
   if ((threadIdx.x & 63) == 0) {
     rmin[threadIdx.x >> 6] = lo;
     rmax[threadIdx.x >> 6] = hi;
+    rsum[threadIdx.x >> 6] = ss;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float* o = partial + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
-    o[0] = fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3]));
-    o[1] = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+    double* o = partial + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = (double)fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3]));
+    o[1] = (double)fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+    o[2] = (rsum[0] + rsum[1]) + (rsum[2] + rsum[3]);
   }
 }
 
@@ -226,11 +233,12 @@ constexpr int kManySlices = 16;
 
 extern "C" int64_t ndmps_minmax_many_workspace_bytes(int count) {
   if (count <= 0) return 0;
-  return (int64_t)count * (8 + 8 + 2 * 4 * kManySlices) + 1024;
+  return (int64_t)count * (8 + 8 + 3 * 8 * kManySlices) + 1024;
 }
 
 extern "C" int ndmps_minmax_many_f32(int count, const float* const* h_ptrs, const int64_t* h_lens,
-                                     float* h_out, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+                                     float* h_out, double* h_sumsq, void* d_ws, int64_t ws_bytes,
+                                     ndmps_stream_t stream) {
   NDMPS_REQUIRE(count >= 1 && count <= 65535 && h_ptrs && h_lens && h_out, "bad minmax_many argument");
   if (!d_ws || ws_bytes < ndmps_minmax_many_workspace_bytes(count)) {
     ndmps::set_error("minmax_many workspace too small");
@@ -241,22 +249,25 @@ extern "C" int ndmps_minmax_many_f32(int count, const float* const* h_ptrs, cons
   char* base = (char*)d_ws;
   const float** d_ptrs = (const float**)base;
   int64_t* d_lens = (int64_t*)(base + ndmps::round_up((int64_t)count * 8, 256));
-  float* partial = (float*)((char*)d_lens + ndmps::round_up((int64_t)count * 8, 256));
+  double* partial = (double*)((char*)d_lens + ndmps::round_up((int64_t)count * 8, 256));
   NDMPS_CHECK_HIP(hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(float*) * count, hipMemcpyHostToDevice, s));
   NDMPS_CHECK_HIP(hipMemcpyAsync(d_lens, h_lens, sizeof(int64_t) * count, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(minmax_many_kernel, dim3(kManySlices, count), dim3(256), 0, s, d_ptrs, d_lens, partial);
   NDMPS_LAUNCH_CHECK();
-  std::vector<float> host((size_t)count * kManySlices * 2);
-  NDMPS_CHECK_HIP(hipMemcpyAsync(host.data(), partial, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  std::vector<double> host((size_t)count * kManySlices * 3);
+  NDMPS_CHECK_HIP(hipMemcpyAsync(host.data(), partial, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < count; ++i) {
-    float lo = FLT_MAX, hi = -FLT_MAX;
+    double lo = FLT_MAX, hi = -FLT_MAX, ss = 0.0;
     for (int j = 0; j < kManySlices; ++j) {
-      lo = std::min(lo, host[2 * ((size_t)i * kManySlices + j)]);
-      hi = std::max(hi, host[2 * ((size_t)i * kManySlices + j) + 1]);
+      const double* o = &host[3 * ((size_t)i * kManySlices + j)];
+      lo = std::min(lo, o[0]);
+      hi = std::max(hi, o[1]);
+      ss += o[2];
     }
-    h_out[2 * i] = lo;
-    h_out[2 * i + 1] = hi;
+    h_out[2 * i] = (float)lo;
+    h_out[2 * i + 1] = (float)hi;
+    if (h_sumsq) h_sumsq[i] = ss;
   }
   return NDMPS_OK;
 }

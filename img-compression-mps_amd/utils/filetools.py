@@ -43,22 +43,25 @@ def minmax(t):
     return float(lo.value), float(hi.value)
 
 
-def minmax_many(tensors):
-    """[(min, max)] of several device fp32 tensors: one launch, one synchronisation."""
+def minmax_many(tensors, with_sumsq=False):
+    """[(min, max)] of several device fp32 tensors: one launch, one synchronisation.
+    ``with_sumsq=True`` also returns the fp64 sums of squares."""
     import torch
 
     lib = _lib.load()
     ts = [t if t.is_contiguous() else t.contiguous() for t in tensors]
     count = len(ts)
     if count == 0:
-        return []
+        return ([], []) if with_sumsq else []
     nbytes = lib.ndmps_minmax_many_workspace_bytes(count)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=ts[0].device)
     ptrs = (C.c_void_p * count)(*[t.data_ptr() for t in ts])
     lens = _lib.i64_array([t.numel() for t in ts])
     out = (C.c_float * (2 * count))()
-    _lib.check(lib.ndmps_minmax_many_f32(count, ptrs, lens, out, ws.data_ptr(), nbytes, _lib.stream_ptr()))
-    return [(float(out[2 * i]), float(out[2 * i + 1])) for i in range(count)]
+    ss = (C.c_double * count)()
+    _lib.check(lib.ndmps_minmax_many_f32(count, ptrs, lens, out, ss, ws.data_ptr(), nbytes, _lib.stream_ptr()))
+    mm = [(float(out[2 * i]), float(out[2 * i + 1])) for i in range(count)]
+    return (mm, [float(v) for v in ss]) if with_sumsq else mm
 
 
 def scale_to_dtype(t, dtype=np.uint8):

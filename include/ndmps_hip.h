@@ -92,11 +92,13 @@ int ndmps_sumsq_f32(const float* d_x, int64_t n, double* h_out, void* d_ws, int6
                     ndmps_stream_t stream);
 int ndmps_minmax_f32(const float* d_x, int64_t n, float* h_min, float* h_max, void* d_ws,
                      int64_t ws_bytes, ndmps_stream_t stream);
-/* min/max of `count` tensors with one launch and one synchronisation (boundary_list of all
- * cores, core/ndmps.py:80-82): h_ptrs / h_lens are host arrays, h_out gets (min, max) pairs */
+/* min/max (and optionally the fp64 sum of squares) of `count` tensors with one launch and one
+ * synchronisation (boundary_list of all cores, core/ndmps.py:80-82): h_ptrs / h_lens are host
+ * arrays, h_out gets (min, max) pairs, h_sumsq (may be NULL) one double per tensor */
 int64_t ndmps_minmax_many_workspace_bytes(int count);
 int ndmps_minmax_many_f32(int count, const float* const* h_ptrs, const int64_t* h_lens,
-                          float* h_out, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+                          float* h_out, double* h_sumsq, void* d_ws, int64_t ws_bytes,
+                          ndmps_stream_t stream);
 int ndmps_scale_f32(float* d_x, int64_t n, double factor, ndmps_stream_t stream);
 int64_t ndmps_reduce_workspace_bytes(void);
 

@@ -339,6 +339,10 @@ def test_roundtrip_exact(ndmps_obj, tensor):
 def test_norm_option(tensor):
     obj = NDMPS.from_tensor(tensor, norm=True)
     assert math.isclose(obj.norm_value, 1.0, rel_tol=1e-6)
+    fast = obj.norm_value          # ||site 0|| of the right-canonical sweep output
+    obj.update_norm()              # full overlap contraction, as the reference
+    assert math.isclose(obj.norm_value, fast, rel_tol=2e-6)
+    assert math.isclose(obj.norm_value ** 2, obj.mps @ obj.mps, rel_tol=1e-12)
 
 
 def test_compression_reduces_elements(ndmps_obj):
