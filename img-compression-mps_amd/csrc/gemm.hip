@@ -293,6 +293,211 @@ gram_reduce_kernel(const double* __restrict__ partial, double* __restrict__ G, i
   }
 }
 
+// ----------------------------------------------------------------------------------
+// Gram for wide column counts (n >= 128): a workgroup owns a 128 x 128 tile of the upper
+// triangle over a slab of rows; 32-row chunks of the two 128-column panels are staged in LDS
+// (16-byte global loads, each element of A fetched once per tile row/column instead of once
+// per 64-wide tile and per lane), the next chunk is prefetched into registers while the four
+// waves (2 x 2, 64 x 64 each, 16 f64 MFMA accumulators) consume the current one.
+// LDS rows are padded by 16 floats: a fragment read (4 rows x 16 columns) is conflict-free.
+// ----------------------------------------------------------------------------------
+constexpr int GW_TS = 128;   // tile edge
+constexpr int GW_KB = 32;    // rows per staged chunk
+constexpr int GW_LD = GW_TS + 16;
+
+__global__ void __launch_bounds__(256)
+gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+                 double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab, int vec_ok) {
+  __shared__ float Ai[GW_KB][GW_LD];
+  __shared__ float Aj[GW_KB][GW_LD];
+
+  int tile = blockIdx.x, ti = 0;
+  while (tile >= n_tiles_1d - ti) {
+    tile -= n_tiles_1d - ti;
+    ++ti;
+  }
+  const int tj = ti + tile;
+  const bool diag = ti == tj;
+  const int64_t i0 = (int64_t)ti * GW_TS, j0 = (int64_t)tj * GW_TS;
+  const int64_t r_begin = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r_end = min(m, r_begin + rows_per_slab);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane >> 4, lc = lane & 15;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  // staging map: 32 rows x 32 float4 per panel = 1024 float4, 4 per thread
+  float4 pi[4], pj[4];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int e = tid + 256 * v;
+      const int rr = e >> 5, c4 = (e & 31) * 4;
+      const int64_t row = r0 + rr;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+      if (row < r_end) {
+        const float* base = A + row * lda;
+        if (vec_ok && i0 + c4 + 3 < n) x = *reinterpret_cast<const float4*>(base + i0 + c4);
+        else {
+          if (i0 + c4 + 0 < n) x.x = base[i0 + c4 + 0];
+          if (i0 + c4 + 1 < n) x.y = base[i0 + c4 + 1];
+          if (i0 + c4 + 2 < n) x.z = base[i0 + c4 + 2];
+          if (i0 + c4 + 3 < n) x.w = base[i0 + c4 + 3];
+        }
+        if (!diag) {
+          if (vec_ok && j0 + c4 + 3 < n) y = *reinterpret_cast<const float4*>(base + j0 + c4);
+          else {
+            if (j0 + c4 + 0 < n) y.x = base[j0 + c4 + 0];
+            if (j0 + c4 + 1 < n) y.y = base[j0 + c4 + 1];
+            if (j0 + c4 + 2 < n) y.z = base[j0 + c4 + 2];
+            if (j0 + c4 + 3 < n) y.w = base[j0 + c4 + 3];
+          }
+        }
+      }
+      pi[v] = x;
+      pj[v] = y;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int e = tid + 256 * v;
+      const int rr = e >> 5, c4 = (e & 31) * 4;
+      *reinterpret_cast<float4*>(&Ai[rr][c4]) = pi[v];
+      if (!diag) *reinterpret_cast<float4*>(&Aj[rr][c4]) = pj[v];
+    }
+  };
+
+  fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += GW_KB) {
+    __syncthreads();  // previous chunk fully consumed
+    stash();
+    __syncthreads();
+    if (r0 + GW_KB < r_end) fetch(r0 + GW_KB);  // prefetch under the MFMAs
+    const float (*Bj)[GW_LD] = diag ? Ai : Aj;
+#pragma unroll
+    for (int k0 = 0; k0 < GW_KB; k0 += 4) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        av[a] = (double)Ai[k0 + lr][wr * 64 + 16 * a + lc];
+        bv[a] = (double)Bj[k0 + lr][wc * 64 + 16 * a + lc];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  double* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GW_TS * GW_TS);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int rr = wr * 64 + 16 * a + lr + 4 * reg, cc = wc * 64 + 16 * b + lc;
+        out[rr * GW_TS + cc] = acc[a][b][reg];
+      }
+}
+
+// slab reduce for the 128-wide tiles: grid (n_tiles, 128*128/256)
+__global__ void __launch_bounds__(256)
+gram_wide_reduce_kernel(const double* __restrict__ partial, double* __restrict__ G, int64_t n,
+                        int n_tiles_1d, int n_tiles, int n_slabs) {
+  int tile = blockIdx.x, ti = 0;
+  while (tile >= n_tiles_1d - ti) {
+    tile -= n_tiles_1d - ti;
+    ++ti;
+  }
+  const int tj = ti + tile;
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  const double* src = partial + (int64_t)blockIdx.x * (GW_TS * GW_TS) + e;
+  const int64_t slab_stride = (int64_t)n_tiles * (GW_TS * GW_TS);
+  double s = 0.0;
+  int sl = 0;
+  for (; sl + 4 <= n_slabs; sl += 4) {
+    const double v0 = src[(sl + 0) * slab_stride], v1 = src[(sl + 1) * slab_stride];
+    const double v2 = src[(sl + 2) * slab_stride], v3 = src[(sl + 3) * slab_stride];
+    s = (((s + v0) + v1) + v2) + v3;
+  }
+  for (; sl < n_slabs; ++sl) s += src[sl * slab_stride];
+  const int64_t r = (int64_t)ti * GW_TS + e / GW_TS, c = (int64_t)tj * GW_TS + e % GW_TS;
+  if (r < n && c < n && (ti != tj || c >= r)) {
+    G[r * n + c] = s;
+    G[c * n + r] = s;
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// Gram for very narrow matrices (n <= 8, the first site of the sweep: m = N / d rows of d
+// voxels): pure streaming.  One thread per row (grid-stride), the 36 products of a row go to
+// fp64 registers; wave shuffle + LDS fold; one partial per workgroup, summed in fixed order.
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gram_small_kernel(const float* __restrict__ A, int64_t m, int n, int64_t lda, double* __restrict__ partial,
+                  int vec_ok) {
+  __shared__ double red[4][36];
+  double acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m; r += stride) {
+    float x[8];
+    const float* row = A + r * lda;
+    if (vec_ok) {
+      const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] = c < n ? row[c] : 0.f;
+    }
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = i; j < 8; ++j) acc[idx++] += (double)x[i] * (double)x[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) {
+    double v = acc[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 36)
+    partial[(int64_t)blockIdx.x * 36 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(64)
+gram_small_reduce_kernel(const double* __restrict__ partial, int n_blocks, double* __restrict__ G, int n) {
+  const int e = threadIdx.x;
+  if (e >= 36) return;
+  double s = 0.0;
+  for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * 36 + e];
+  int i = 0, rem = e;  // unrank e -> (i, j), j >= i
+  while (rem >= 8 - i) {
+    rem -= 8 - i;
+    ++i;
+  }
+  const int j = i + rem;
+  if (i < n && j < n) {
+    G[i * n + j] = s;
+    G[j * n + i] = s;
+  }
+}
+
+constexpr int kGramSmallBlocks = 512;
+
 struct GramGeom {
   int T;          // 16-wide sub-tiles per tile edge
   int tiles_1d;
@@ -341,8 +546,28 @@ extern "C" int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t
   return launch_gemm<double, 64, 64, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
 }
 
+// geometry of the 128-wide path: ~2 workgroups per CU, slabs a multiple of the 32-row chunk
+GramGeom gram_wide_geometry(int64_t m, int64_t n) {
+  GramGeom g;
+  g.T = 8;
+  g.tiles_1d = (int)ndmps::ceil_div(n, GW_TS);
+  g.n_tiles = g.tiles_1d * (g.tiles_1d + 1) / 2;
+  const int64_t want = std::max<int64_t>(1, (2 * ndmps::kNumCU) / g.n_tiles);
+  g.rows_per_slab = ndmps::round_up(std::max<int64_t>(ndmps::ceil_div(m, want), 4 * GW_KB), GW_KB);
+  g.n_slabs = (int)std::max<int64_t>(1, ndmps::ceil_div(m, g.rows_per_slab));
+  return g;
+}
+
+inline bool gram_use_wide(int64_t m, int64_t n) { return n >= 128 && m >= 256; }
+inline bool gram_use_small(int64_t n) { return n <= 8; }
+
 extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
   if (m <= 0 || n <= 0) return 0;
+  if (gram_use_small(n)) return (int64_t)kGramSmallBlocks * 36 * 8 + 256;
+  if (gram_use_wide(m, n)) {
+    GramGeom g = gram_wide_geometry(m, n);
+    return (int64_t)g.n_slabs * g.n_tiles * GW_TS * GW_TS * (int64_t)sizeof(double) + 256;
+  }
   GramGeom g = gram_geometry(m, n);
   const int ts = 16 * g.T;
   return (int64_t)g.n_slabs * g.n_tiles * ts * ts * (int64_t)sizeof(double) + 256;
@@ -358,10 +583,29 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
                      (long long)ndmps_gram_workspace_bytes(m, n));
     return NDMPS_EWORKSPACE;
   }
-  GramGeom g = gram_geometry(m, n);
-  NDMPS_REQUIRE(g.n_slabs < 65536, "Gram slab count %d exceeds grid.y", g.n_slabs);
   hipStream_t s = (hipStream_t)stream;
   double* partial = (double*)d_ws;
+  const int vec_ok = (lda % 4 == 0 && n % 4 == 0 && ((uintptr_t)d_A % 16) == 0) ? 1 : 0;
+  if (gram_use_small(n)) {
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(m, 256 * 8), 1), kGramSmallBlocks);
+    hipLaunchKernelGGL(gram_small_kernel, dim3(blocks), dim3(256), 0, s, d_A, m, (int)n, lda, partial,
+                       (vec_ok && n == 8) ? 1 : 0);
+    hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(1), dim3(64), 0, s, partial, blocks, d_G, (int)n);
+    NDMPS_LAUNCH_CHECK();
+    return NDMPS_OK;
+  }
+  if (gram_use_wide(m, n)) {
+    GramGeom gw = gram_wide_geometry(m, n);
+    NDMPS_REQUIRE(gw.n_slabs < 65536, "Gram slab count %d exceeds grid.y", gw.n_slabs);
+    hipLaunchKernelGGL(gram_wide_kernel, dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda, partial,
+                       gw.tiles_1d, gw.rows_per_slab, vec_ok);
+    hipLaunchKernelGGL(gram_wide_reduce_kernel, dim3(gw.n_tiles, GW_TS * GW_TS / 256), dim3(256), 0, s, partial,
+                       d_G, n, gw.tiles_1d, gw.n_tiles, gw.n_slabs);
+    NDMPS_LAUNCH_CHECK();
+    return NDMPS_OK;
+  }
+  GramGeom g = gram_geometry(m, n);
+  NDMPS_REQUIRE(g.n_slabs < 65536, "Gram slab count %d exceeds grid.y", g.n_slabs);
   dim3 grid(g.n_tiles, g.n_slabs);
 #define NDMPS_GRAM(TT)                                                                              \
   do {                                                                                              \

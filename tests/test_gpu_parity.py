@@ -165,7 +165,8 @@ def test_sgemm_matches_fma_chain_on_integers_asymmetric():
 
 
 @pytest.mark.parametrize("m,n", [(64, 8), (1000, 8), (4096, 64), (777, 33), (5000, 130), (16, 16), (3, 20),
-                                 (20000, 512), (100, 257)])
+                                 (20000, 512), (100, 257), (4096, 512), (300, 128), (1001, 136), (200001, 8),
+                                 (1000, 5), (333, 680), (257, 131), (70000, 2)])
 def test_gram_fp64(m, n):
     lib = _lib.load()
     a = np.random.default_rng(m + n).standard_normal((m, n)).astype(np.float32)
