@@ -148,20 +148,31 @@ __global__ void __launch_bounds__(256) blk_scale_kernel(BatchDesc* __restrict__ 
   }
 }
 
-// position of every index after sorting the diagonal descending (ties by index)
+__device__ __forceinline__ int block_sum_int(int v, int* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// position of every index after sorting the diagonal descending (ties by index);
+// one workgroup per index (grid.x = n_max), the count is a block reduction
 __global__ void __launch_bounds__(256) blk_order_kernel(const BatchDesc* __restrict__ desc, Work w) {
+  __shared__ int red[4];
   const BatchDesc& d = desc[blockIdx.y];
   const double* G = d.G_in;
   const int n = d.n;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x;
   if (i >= n) return;
   const double di = G[(int64_t)i * n + i];
   int rk = 0;
-  for (int j = 0; j < n; ++j) {
+  for (int j = threadIdx.x; j < n; j += 256) {
     const double dj = G[(int64_t)j * n + j];
     rk += (dj > di) || (dj == di && j < i);
   }
-  w.pos[(int64_t)blockIdx.y * w.np + i] = rk;
+  rk = block_sum_int(rk, red);
+  if (threadIdx.x == 0) w.pos[(int64_t)blockIdx.y * w.np + i] = rk;
 }
 
 // G[0] = P^T sym(G) P (padded with zeros), V = P on the real indices, identity on the padding
@@ -497,30 +508,59 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
 }
 
 // ---------------------------------------------------------------------------- finish
+// rank of every eigenvalue (descending, ties by index) and sign of its eigenvector (largest
+// component positive; ties -> lowest row): one workgroup per index, block reductions
 __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restrict__ desc, Work w) {
+  __shared__ int red[4];
+  __shared__ double best_v[4];
+  __shared__ int best_r[4];
   const BatchDesc& d = desc[blockIdx.y];
   const int n = d.n, np = w.np;
   const double* G = w.G[d.final_buf] + (int64_t)blockIdx.y * np * np;
   const double* V = w.V + (int64_t)blockIdx.y * np * np;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x;
   if (i >= n) return;
   const double wi = G[(int64_t)i * np + i];
   int rk = 0;
-  for (int j = 0; j < n; ++j) {
+  for (int j = threadIdx.x; j < n; j += 256) {
     const double wj = G[(int64_t)j * np + j];
     rk += (wj > wi) || (wj == wi && j < i);
   }
-  double best = 0.0, sg = 1.0;
-  for (int r = 0; r < n; ++r) {
-    const double v = V[(int64_t)r * np + i];
-    if (fabs(v) > best) {
-      best = fabs(v);
-      sg = v < 0.0 ? -1.0 : 1.0;
+  rk = block_sum_int(rk, red);
+  // arg max |V[r][i]| with the lowest r on ties (matches a sequential scan with '>')
+  double bv = -1.0;
+  int br = 0x7fffffff;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const double a = fabs(V[(int64_t)r * np + i]);
+    if (a > bv) {
+      bv = a;
+      br = r;
     }
   }
-  w.pos[(int64_t)blockIdx.y * np + i] = rk;
-  w.sign[(int64_t)blockIdx.y * np + i] = sg;
-  d.w_out[rk] = wi;
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_down(bv, off, 64);
+    const int orr = __shfl_down(br, off, 64);
+    if (ov > bv || (ov == bv && orr < br)) {
+      bv = ov;
+      br = orr;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    best_v[threadIdx.x >> 6] = bv;
+    best_r[threadIdx.x >> 6] = br;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (best_v[k] > bv || (best_v[k] == bv && best_r[k] < br)) {
+        bv = best_v[k];
+        br = best_r[k];
+      }
+    const double v = br < n ? V[(int64_t)br * np + i] : 1.0;
+    w.pos[(int64_t)blockIdx.y * np + i] = rk;
+    w.sign[(int64_t)blockIdx.y * np + i] = v < 0.0 ? -1.0 : 1.0;
+    d.w_out[rk] = wi;
+  }
 }
 
 __global__ void __launch_bounds__(256) blk_gather_kernel(const BatchDesc* __restrict__ desc, Work w) {
@@ -595,7 +635,7 @@ int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, v
   const unsigned B = (unsigned)batch;
   const int fill_grid = (int)std::min<int64_t>(ndmps::ceil_div((int64_t)np * np, 256), 1024);
   hipLaunchKernelGGL(blk_scale_kernel, dim3(1, B), dim3(256), 0, s, desc);
-  hipLaunchKernelGGL(blk_order_kernel, dim3((unsigned)ndmps::ceil_div(n_max, 256), B), dim3(256), 0, s, desc, w);
+  hipLaunchKernelGGL(blk_order_kernel, dim3((unsigned)n_max, B), dim3(256), 0, s, desc, w);
   hipLaunchKernelGGL(blk_init_kernel, dim3(fill_grid, B), dim3(256), 0, s, desc, w);
   hipLaunchKernelGGL(blk_scatter_kernel, dim3(fill_grid, B), dim3(256), 0, s, desc, w);
   NDMPS_LAUNCH_CHECK();
@@ -638,7 +678,7 @@ int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, v
                      kMaxSweepsBlock, (long long)n_max, remaining, batch);
     return NDMPS_ENOCONV;
   }
-  hipLaunchKernelGGL(blk_rank_kernel, dim3((unsigned)ndmps::ceil_div(n_max, 256), B), dim3(256), 0, s, desc, w);
+  hipLaunchKernelGGL(blk_rank_kernel, dim3((unsigned)n_max, B), dim3(256), 0, s, desc, w);
   const int gather_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * n_max, 256), 2048);
   hipLaunchKernelGGL(blk_gather_kernel, dim3(gather_grid, B), dim3(256), 0, s, desc, w);
   NDMPS_LAUNCH_CHECK();

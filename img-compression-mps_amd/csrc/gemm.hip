@@ -260,37 +260,64 @@ gram_partial_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t l
   for (int e = tid; e < TS * TS; e += 256) out[e] = red[e / TS][e % TS];
 }
 
-// grid: (n_tiles, TS*TS/256); one thread per tile element, slabs summed in fixed order
-template <int T>
+// Slab reduce, fixed summation order (deterministic), in up to two levels so that no thread
+// walks more than ~32 slabs: grid (n_tiles, TS*TS/256, n_groups).  Group g sums slabs
+// [g*per_group, (g+1)*per_group); `final` writes the (mirrored) tile into G, otherwise the group
+// sums go to `out` laid out like a partial buffer with n_groups slabs.
+template <int TS>
 __global__ void __launch_bounds__(256)
-gram_reduce_kernel(const double* __restrict__ partial, double* __restrict__ G, int64_t n,
-                   int n_tiles_1d, int n_tiles, int n_slabs) {
-  constexpr int TS = 16 * T;
+tile_reduce_kernel(const double* __restrict__ partial, int n_slabs, int per_group, int n_tiles_1d,
+                   int n_tiles, double* __restrict__ out, double* __restrict__ G, int64_t n, int final) {
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= TS * TS) return;
+  const int s0 = blockIdx.z * per_group, s1 = min(n_slabs, s0 + per_group);
+  const double* src = partial + (int64_t)blockIdx.x * (TS * TS) + e;
+  const int64_t slab_stride = (int64_t)n_tiles * (TS * TS);
+  double s = 0.0;
+  int sl = s0;
+  for (; sl + 4 <= s1; sl += 4) {
+    const double v0 = src[(sl + 0) * slab_stride], v1 = src[(sl + 1) * slab_stride];
+    const double v2 = src[(sl + 2) * slab_stride], v3 = src[(sl + 3) * slab_stride];
+    s = (((s + v0) + v1) + v2) + v3;
+  }
+  for (; sl < s1; ++sl) s += src[sl * slab_stride];
+  if (!final) {
+    out[((int64_t)blockIdx.z * n_tiles + blockIdx.x) * (TS * TS) + e] = s;
+    return;
+  }
   int tile = blockIdx.x, ti = 0;
   while (tile >= n_tiles_1d - ti) {
     tile -= n_tiles_1d - ti;
     ++ti;
   }
   const int tj = ti + tile;
-  const int e = blockIdx.y * 256 + threadIdx.x;
-  if (e >= TS * TS) return;
-  const double* src = partial + (int64_t)blockIdx.x * (TS * TS) + e;
-  const int64_t slab_stride = (int64_t)n_tiles * (TS * TS);
-  double s = 0.0;
-  int sl = 0;
-  for (; sl + 4 <= n_slabs; sl += 4) {
-    const double v0 = src[(sl + 0) * slab_stride], v1 = src[(sl + 1) * slab_stride];
-    const double v2 = src[(sl + 2) * slab_stride], v3 = src[(sl + 3) * slab_stride];
-    s = (((s + v0) + v1) + v2) + v3;
-  }
-  for (; sl < n_slabs; ++sl) s += src[sl * slab_stride];
   const int64_t r = (int64_t)ti * TS + e / TS, c = (int64_t)tj * TS + e % TS;
-  if (r < n && c < n) {
-    if (ti != tj || c >= r) {  // diagonal tiles: upper part mirrored, so G is exactly symmetric
-      G[r * n + c] = s;
-      G[c * n + r] = s;
-    }
+  if (r < n && c < n && (ti != tj || c >= r)) {  // diagonal tiles: upper part mirrored -> exactly symmetric
+    G[r * n + c] = s;
+    G[c * n + r] = s;
   }
+}
+
+constexpr int kReduceGroup = 16;
+
+template <int TS>
+int launch_tile_reduce(double* partial, int n_slabs, int n_tiles_1d, int n_tiles, double* G, int64_t n,
+                       hipStream_t s) {
+  const unsigned ey = (TS * TS + 255) / 256;
+  if (n_slabs <= 2 * kReduceGroup) {
+    hipLaunchKernelGGL(tile_reduce_kernel<TS>, dim3(n_tiles, ey, 1), dim3(256), 0, s, partial, n_slabs, n_slabs,
+                       n_tiles_1d, n_tiles, (double*)nullptr, G, n, 1);
+  } else {
+    // level 1 writes its group sums behind the slabs (the workspace has room for them)
+    const int groups = (n_slabs + kReduceGroup - 1) / kReduceGroup;
+    double* lvl = partial + (int64_t)n_slabs * n_tiles * (TS * TS);
+    hipLaunchKernelGGL(tile_reduce_kernel<TS>, dim3(n_tiles, ey, groups), dim3(256), 0, s, partial, n_slabs,
+                       kReduceGroup, n_tiles_1d, n_tiles, lvl, G, n, 0);
+    hipLaunchKernelGGL(tile_reduce_kernel<TS>, dim3(n_tiles, ey, 1), dim3(256), 0, s, lvl, groups, groups,
+                       n_tiles_1d, n_tiles, (double*)nullptr, G, n, 1);
+  }
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
 }
 
 // ----------------------------------------------------------------------------------
@@ -409,34 +436,6 @@ gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
       }
 }
 
-// slab reduce for the 128-wide tiles: grid (n_tiles, 128*128/256)
-__global__ void __launch_bounds__(256)
-gram_wide_reduce_kernel(const double* __restrict__ partial, double* __restrict__ G, int64_t n,
-                        int n_tiles_1d, int n_tiles, int n_slabs) {
-  int tile = blockIdx.x, ti = 0;
-  while (tile >= n_tiles_1d - ti) {
-    tile -= n_tiles_1d - ti;
-    ++ti;
-  }
-  const int tj = ti + tile;
-  const int e = blockIdx.y * 256 + threadIdx.x;
-  const double* src = partial + (int64_t)blockIdx.x * (GW_TS * GW_TS) + e;
-  const int64_t slab_stride = (int64_t)n_tiles * (GW_TS * GW_TS);
-  double s = 0.0;
-  int sl = 0;
-  for (; sl + 4 <= n_slabs; sl += 4) {
-    const double v0 = src[(sl + 0) * slab_stride], v1 = src[(sl + 1) * slab_stride];
-    const double v2 = src[(sl + 2) * slab_stride], v3 = src[(sl + 3) * slab_stride];
-    s = (((s + v0) + v1) + v2) + v3;
-  }
-  for (; sl < n_slabs; ++sl) s += src[sl * slab_stride];
-  const int64_t r = (int64_t)ti * GW_TS + e / GW_TS, c = (int64_t)tj * GW_TS + e % GW_TS;
-  if (r < n && c < n && (ti != tj || c >= r)) {
-    G[r * n + c] = s;
-    G[c * n + r] = s;
-  }
-}
-
 // ----------------------------------------------------------------------------------
 // Gram for very narrow matrices (n <= 8, the first site of the sweep: m = N / d rows of d
 // voxels): pure streaming.  One thread per row (grid-stride), the 36 products of a row go to
@@ -478,12 +477,19 @@ gram_small_kernel(const float* __restrict__ A, int64_t m, int n, int64_t lda, do
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 gram_small_reduce_kernel(const double* __restrict__ partial, int n_blocks, double* __restrict__ G, int n) {
-  const int e = threadIdx.x;
-  if (e >= 36) return;
+  __shared__ double part[7][36];
+  const int e = threadIdx.x % 36, grp = threadIdx.x / 36;  // 7 groups of 36 threads (252 used)
+  if (grp < 7) {
+    double acc = 0.0;
+    for (int b = grp; b < n_blocks; b += 7) acc += partial[(int64_t)b * 36 + e];
+    part[grp][e] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 36) return;
   double s = 0.0;
-  for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * 36 + e];
+  for (int k = 0; k < 7; ++k) s += part[k][e];
   int i = 0, rem = e;  // unrank e -> (i, j), j >= i
   while (rem >= 8 - i) {
     rem -= 8 - i;
@@ -496,7 +502,7 @@ gram_small_reduce_kernel(const double* __restrict__ partial, int n_blocks, doubl
   }
 }
 
-constexpr int kGramSmallBlocks = 512;
+constexpr int kGramSmallBlocks = 256;
 
 struct GramGeom {
   int T;          // 16-wide sub-tiles per tile edge
@@ -513,7 +519,7 @@ GramGeom gram_geometry(int64_t m, int64_t n) {
   g.tiles_1d = (int)ndmps::ceil_div(n, ts);
   g.n_tiles = g.tiles_1d * (g.tiles_1d + 1) / 2;
   // aim at ~4 workgroups per CU; every slab is a multiple of 16 rows (4 waves x 4 rows)
-  int64_t want = std::max<int64_t>(1, (4 * ndmps::kNumCU) / g.n_tiles);
+  int64_t want = std::max<int64_t>(1, (2 * ndmps::kNumCU) / g.n_tiles);
   int64_t rows = ndmps::round_up(std::max<int64_t>(ndmps::ceil_div(m, want), 64), 16);
   g.rows_per_slab = rows;
   g.n_slabs = (int)std::max<int64_t>(1, ndmps::ceil_div(m, rows));
@@ -566,11 +572,12 @@ extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
   if (gram_use_small(n)) return (int64_t)kGramSmallBlocks * 36 * 8 + 256;
   if (gram_use_wide(m, n)) {
     GramGeom g = gram_wide_geometry(m, n);
-    return (int64_t)g.n_slabs * g.n_tiles * GW_TS * GW_TS * (int64_t)sizeof(double) + 256;
+    return (int64_t)(g.n_slabs + g.n_slabs / kReduceGroup + 2) * g.n_tiles * GW_TS * GW_TS *
+               (int64_t)sizeof(double) + 256;
   }
   GramGeom g = gram_geometry(m, n);
   const int ts = 16 * g.T;
-  return (int64_t)g.n_slabs * g.n_tiles * ts * ts * (int64_t)sizeof(double) + 256;
+  return (int64_t)(g.n_slabs + g.n_slabs / kReduceGroup + 2) * g.n_tiles * ts * ts * (int64_t)sizeof(double) + 256;
 }
 
 extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
@@ -590,7 +597,7 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(m, 256 * 8), 1), kGramSmallBlocks);
     hipLaunchKernelGGL(gram_small_kernel, dim3(blocks), dim3(256), 0, s, d_A, m, (int)n, lda, partial,
                        (vec_ok && n == 8) ? 1 : 0);
-    hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(1), dim3(64), 0, s, partial, blocks, d_G, (int)n);
+    hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(1), dim3(256), 0, s, partial, blocks, d_G, (int)n);
     NDMPS_LAUNCH_CHECK();
     return NDMPS_OK;
   }
@@ -599,10 +606,8 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
     NDMPS_REQUIRE(gw.n_slabs < 65536, "Gram slab count %d exceeds grid.y", gw.n_slabs);
     hipLaunchKernelGGL(gram_wide_kernel, dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda, partial,
                        gw.tiles_1d, gw.rows_per_slab, vec_ok);
-    hipLaunchKernelGGL(gram_wide_reduce_kernel, dim3(gw.n_tiles, GW_TS * GW_TS / 256), dim3(256), 0, s, partial,
-                       d_G, n, gw.tiles_1d, gw.n_tiles, gw.n_slabs);
     NDMPS_LAUNCH_CHECK();
-    return NDMPS_OK;
+    return launch_tile_reduce<GW_TS>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
   }
   GramGeom g = gram_geometry(m, n);
   NDMPS_REQUIRE(g.n_slabs < 65536, "Gram slab count %d exceeds grid.y", g.n_slabs);
@@ -611,13 +616,12 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
   do {                                                                                              \
     hipLaunchKernelGGL(gram_partial_kernel<TT>, grid, dim3(256), 0, s, d_A, m, n, lda, partial,     \
                        g.tiles_1d, g.rows_per_slab);                                                \
-    hipLaunchKernelGGL(gram_reduce_kernel<TT>, dim3(g.n_tiles, (16 * TT * 16 * TT + 255) / 256),   \
-                       dim3(256), 0, s, partial, d_G, n, g.tiles_1d, g.n_tiles, g.n_slabs);         \
+    NDMPS_LAUNCH_CHECK();                                                                           \
+    return launch_tile_reduce<16 * TT>(partial, g.n_slabs, g.tiles_1d, g.n_tiles, d_G, n, s);       \
   } while (0)
   if (g.T == 1) NDMPS_GRAM(1);
   else if (g.T == 2) NDMPS_GRAM(2);
   else NDMPS_GRAM(4);
 #undef NDMPS_GRAM
-  NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }

@@ -102,10 +102,13 @@ int64_t kept_rank(const std::vector<double>& sigma, double cutoff, int64_t max_b
 // max(1024, tiles(n)), 64 x 64 doubles each.
 int64_t gram_ws_bound(int64_t n) {
   const int64_t t1 = ceil_div(n, 64);
-  const int64_t narrow = std::max<int64_t>(1024, t1 * (t1 + 1) / 2) * 4096 * 8 + 256;
-  // 128-wide path: slabs * tiles <= max(512, tiles(n)), 128 x 128 doubles each
+  // (slabs + slabs/16 + 2) * tiles tiles of 64 x 64 doubles, slabs * tiles <= max(512, tiles(n))
+  const int64_t nt1 = t1 * (t1 + 1) / 2;
+  const int64_t narrow = (std::max<int64_t>(512, nt1) * 17 / 16 + 3 * nt1) * 4096 * 8 + 256;
+  // 128-wide path: same bound with 128 x 128 tiles
   const int64_t t2 = ceil_div(n, 128);
-  const int64_t wide = std::max<int64_t>(512, t2 * (t2 + 1) / 2) * 16384 * 8 + 256;
+  const int64_t nt2 = t2 * (t2 + 1) / 2;
+  const int64_t wide = (std::max<int64_t>(512, nt2) * 17 / 16 + 3 * nt2) * 16384 * 8 + 256;
   return std::max(narrow, wide);
 }
 
