@@ -41,6 +41,9 @@ struct DevPlan {
   int64_t tile;               // elements per tile
   const uint32_t* order;      // [tile] site-order position of the k-th smallest source offset
   const int64_t* src_sorted;  // [tile] that source offset
+  int vec4;                   // sorted runs and tile bases are multiples of 4 elements: 4-wide path
+  const uint32_t* vec_tab;    // [tile/4][3]: source offset of the group, then its four site-order
+                              // positions packed as 2 x (lo16 | hi16 << 16)
 };
 
 }  // namespace
@@ -51,6 +54,7 @@ struct HostTables {
   std::vector<std::vector<int64_t>> group_tab;
   std::vector<uint32_t> order;
   std::vector<int64_t> src_sorted;
+  std::vector<uint32_t> vec_tab;
 };
 
 struct ndmps_plan {
@@ -106,35 +110,78 @@ __device__ __forceinline__ int64_t tile_source_base(const DevPlan& p, int64_t ti
   return off;
 }
 
-// One workgroup per tile (grid-stride).  LDS holds the tile in site order.
 template <typename T>
+struct Vec4 {
+  T v[4];
+} __attribute__((aligned(sizeof(T) * 4)));
+
+// One workgroup per tile (grid-stride).  LDS holds the tile in site order.
+// VEC: every sorted run of source offsets is a multiple of 4 elements and 4-aligned, so both sides
+// move 4 elements per lane (16 B for fp32) through a packed per-group table (12 B per 4 elements,
+// L1/L2-resident).
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) encode_tiled_kernel(DevPlan p, const T* __restrict__ src,
                                                            T* __restrict__ dst, int64_t n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   const int tile = (int)p.tile;
+  const uint32_t* __restrict__ tab = p.vec_tab;
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const T* s = src + tile_source_base(p, t);
-    for (int k = threadIdx.x; k < tile; k += 256) lds[p.order[k]] = s[p.src_sorted[k]];
+    if (VEC) {
+      for (int g = threadIdx.x; g < tile / 4; g += 256) {
+        const uint32_t off = tab[3 * g], o01 = tab[3 * g + 1], o23 = tab[3 * g + 2];
+        const Vec4<T> x = *reinterpret_cast<const Vec4<T>*>(s + off);
+        lds[o01 & 0xffffu] = x.v[0];
+        lds[o01 >> 16] = x.v[1];
+        lds[o23 & 0xffffu] = x.v[2];
+        lds[o23 >> 16] = x.v[3];
+      }
+    } else {
+      for (int k = threadIdx.x; k < tile; k += 256) lds[p.order[k]] = s[p.src_sorted[k]];
+    }
     __syncthreads();
     T* d = dst + t * tile;
-    for (int k = threadIdx.x; k < tile; k += 256) d[k] = lds[k];
+    if (VEC) {
+      for (int k = threadIdx.x * 4; k < tile; k += 1024)
+        *reinterpret_cast<Vec4<T>*>(d + k) = *reinterpret_cast<const Vec4<T>*>(lds + k);
+    } else {
+      for (int k = threadIdx.x; k < tile; k += 256) d[k] = lds[k];
+    }
     __syncthreads();
   }
 }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) decode_tiled_kernel(DevPlan p, const T* __restrict__ dense,
                                                            T* __restrict__ out, int64_t n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   const int tile = (int)p.tile;
+  const uint32_t* __restrict__ tab = p.vec_tab;
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const T* d = dense + t * tile;
-    for (int k = threadIdx.x; k < tile; k += 256) lds[k] = d[k];
+    if (VEC) {
+      for (int k = threadIdx.x * 4; k < tile; k += 1024)
+        *reinterpret_cast<Vec4<T>*>(lds + k) = *reinterpret_cast<const Vec4<T>*>(d + k);
+    } else {
+      for (int k = threadIdx.x; k < tile; k += 256) lds[k] = d[k];
+    }
     __syncthreads();
     T* o = out + tile_source_base(p, t);
-    for (int k = threadIdx.x; k < tile; k += 256) o[p.src_sorted[k]] = lds[p.order[k]];
+    if (VEC) {
+      for (int g = threadIdx.x; g < tile / 4; g += 256) {
+        const uint32_t off = tab[3 * g], o01 = tab[3 * g + 1], o23 = tab[3 * g + 2];
+        Vec4<T> x;
+        x.v[0] = lds[o01 & 0xffffu];
+        x.v[1] = lds[o01 >> 16];
+        x.v[2] = lds[o23 & 0xffffu];
+        x.v[3] = lds[o23 >> 16];
+        *reinterpret_cast<Vec4<T>*>(o + off) = x;
+      }
+    } else {
+      for (int k = threadIdx.x; k < tile; k += 256) o[p.src_sorted[k]] = lds[p.order[k]];
+    }
     __syncthreads();
   }
 }
@@ -151,10 +198,46 @@ int upload(ndmps_plan* plan, const std::vector<T>& host, const T** dev_out) {
   return NDMPS_OK;
 }
 
-int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L, const int64_t* f) {
+int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L_in, const int64_t* f_in) {
   DevPlan& dp = plan->dev;
   dp.ndim = ndim;
-  plan->L = L;
+  plan->L = L_in;
+  // Refinement: the LDS tile is made of whole low sites; if the site just above them has a last-
+  // dimension factor divisible by S (tile * S still fits), that site is split into two pseudo-sites
+  // (..., f_last / S) and (1, ..., 1, S).  The flat permutation is unchanged (the last-dimension digit
+  // is the fastest one inside a site index), the tile becomes S times longer along the contiguous
+  // source axis: 64-byte source runs become 128-byte runs for 2^k cubes.
+  std::vector<int64_t> fbuf(f_in, f_in + (size_t)L_in * ndim);
+  int L = L_in;
+  {
+    std::vector<int64_t> sd(L, 1);
+    for (int l = 0; l < L; ++l)
+      for (int j = 0; j < ndim; ++j) sd[l] *= std::max<int64_t>(fbuf[l * ndim + j], 1);
+    int lo = L - 1;
+    int64_t size = sd[L - 1];
+    while (lo - 1 >= 0 && size * sd[lo - 1] <= kTileCap) {
+      --lo;
+      size *= sd[lo];
+    }
+    if (lo > 0 && size >= kTileMin / 2) {
+      const int64_t f_last = fbuf[(lo - 1) * ndim + ndim - 1];
+      int64_t S = 1;
+      for (int64_t c = 2; c <= f_last; ++c)
+        if (f_last % c == 0 && size * c <= kTileCap) S = c;
+      if (S > 1 && S < f_last && L + 1 <= kMaxSites) {
+        std::vector<int64_t> g((size_t)(L + 1) * ndim);
+        for (int l = 0; l < lo; ++l)
+          for (int j = 0; j < ndim; ++j) g[l * ndim + j] = fbuf[l * ndim + j];
+        g[(lo - 1) * ndim + ndim - 1] = f_last / S;
+        for (int j = 0; j < ndim; ++j) g[lo * ndim + j] = (j == ndim - 1) ? S : 1;
+        for (int l = lo; l < L; ++l)
+          for (int j = 0; j < ndim; ++j) g[(l + 1) * ndim + j] = fbuf[l * ndim + j];
+        fbuf.swap(g);
+        ++L;
+      }
+    }
+  }
+  const int64_t* f = fbuf.data();
   int64_t numel = 1;
   for (int j = 0; j < ndim; ++j) {
     NDMPS_REQUIRE(shape[j] > 0, "shape[%d]=%lld must be positive", j, (long long)shape[j]);
@@ -265,6 +348,24 @@ int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L, const in
     for (int64_t k = 0; k < tile; ++k) sorted[k] = low_table[order[k]];
     plan->host.order = order;
     plan->host.src_sorted = sorted;
+    // 4-wide path: tile a multiple of 4, every group of 4 sorted offsets consecutive and 4-aligned,
+    // and every tile base (sum of high-group offsets) a multiple of 4
+    bool vec = (tile % 4 == 0);
+    for (int64_t k = 0; vec && k < tile; k += 4)
+      vec = sorted[k] % 4 == 0 && sorted[k + 1] == sorted[k] + 1 && sorted[k + 2] == sorted[k] + 2 &&
+            sorted[k + 3] == sorted[k] + 3;
+    for (int g = 0; vec && g + 1 < dp.n_groups; ++g)
+      for (int64_t v : plan->host.group_tab[g]) vec = vec && (v % 4 == 0);
+    vec = vec && tile <= 65536 && sorted[tile - 1] < (int64_t)1 << 32;  // packed table field widths
+    dp.vec4 = vec ? 1 : 0;
+    if (vec) {
+      plan->host.vec_tab.resize((size_t)(tile / 4) * 3);
+      for (int64_t g = 0; g < tile / 4; ++g) {
+        plan->host.vec_tab[3 * g] = (uint32_t)sorted[4 * g];
+        plan->host.vec_tab[3 * g + 1] = order[4 * g] | (order[4 * g + 1] << 16);
+        plan->host.vec_tab[3 * g + 2] = order[4 * g + 2] | (order[4 * g + 3] << 16);
+      }
+    }
   }
   return NDMPS_OK;
 }
@@ -276,6 +377,7 @@ int upload_plan(ndmps_plan* plan) {
   if (plan->tiled) {
     NDMPS_TRY(upload(plan, plan->host.order, &dp.order));
     NDMPS_TRY(upload(plan, plan->host.src_sorted, &dp.src_sorted));
+    if (dp.vec4) NDMPS_TRY(upload(plan, plan->host.vec_tab, &dp.vec_tab));
   }
   return NDMPS_OK;
 }
@@ -291,14 +393,21 @@ int launch(const ndmps_plan* plan, const void* in, void* out, bool encode, bool 
   const DevPlan& dp = plan->dev;
   if (plan->tiled && !force_generic) {
     const int64_t n_tiles = dp.numel / dp.tile;
+    // 4-wide accesses also need 4-element-aligned buffers (torch allocations are 256-B aligned)
+    const bool vec = dp.vec4 && ((uintptr_t)in % (4 * sizeof(T)) == 0) && ((uintptr_t)out % (4 * sizeof(T)) == 0);
     const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ndmps::kNumCU * 8);
     const size_t lds = (size_t)dp.tile * sizeof(T);
-    if (encode)
-      hipLaunchKernelGGL(encode_tiled_kernel<T>, dim3(grid), dim3(256), lds, stream, dp, (const T*)in,
-                         (T*)out, n_tiles);
-    else
-      hipLaunchKernelGGL(decode_tiled_kernel<T>, dim3(grid), dim3(256), lds, stream, dp, (const T*)in,
-                         (T*)out, n_tiles);
+    if (encode) {
+      if (vec) hipLaunchKernelGGL((encode_tiled_kernel<T, true>), dim3(grid), dim3(256), lds, stream, dp,
+                                  (const T*)in, (T*)out, n_tiles);
+      else hipLaunchKernelGGL((encode_tiled_kernel<T, false>), dim3(grid), dim3(256), lds, stream, dp,
+                              (const T*)in, (T*)out, n_tiles);
+    } else {
+      if (vec) hipLaunchKernelGGL((decode_tiled_kernel<T, true>), dim3(grid), dim3(256), lds, stream, dp,
+                                  (const T*)in, (T*)out, n_tiles);
+      else hipLaunchKernelGGL((decode_tiled_kernel<T, false>), dim3(grid), dim3(256), lds, stream, dp,
+                              (const T*)in, (T*)out, n_tiles);
+    }
   } else {
     const int grid = grid_for(dp.numel, 256);
     if (encode)
