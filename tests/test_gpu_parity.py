@@ -572,3 +572,70 @@ def test_minmax_many_matches_single():
     ts = [torch.randn(n, device=DEV) for n in (1, 17, 4096, 100003)]
     got = hft.minmax_many(ts)
     assert got == [hft.minmax(t) for t in ts]
+
+
+# ------------------------------------------------------ BASELINE configs at full size (properties)
+def _projection_checks(x, obj, rec, tol=2e-4):
+    """Size-independent properties of a truncated sweep: the reconstruction is an orthogonal
+    projection of the (possibly DCT-transformed) data, so ||x||^2 = ||rec||^2 + ||x - rec||^2 and
+    <x - rec, rec> = 0; the stored norm is ||rec||."""
+    x64 = x.double()
+    r64 = rec.double()
+    nx, nr, ne = float((x64 * x64).sum()), float((r64 * r64).sum()), float(((x64 - r64) ** 2).sum())
+    assert abs(nx - nr - ne) <= tol * nx
+    assert abs(float(((x64 - r64) * r64).sum())) <= tol * nx
+    assert math.isclose(obj.norm_value ** 2, nr, rel_tol=1e-4)
+    return ne / nx
+
+
+def test_config2_256_cubed_chi32_properties_and_idempotence():
+    """BASELINE configs[1]: 256^3 fp32, chi = 32 (oracle-sized cases are covered at 128^3)."""
+    x = torch.from_numpy(synthetic_mri((256, 256, 256), seed=2025)).to(DEV)
+    obj = NDMPS.from_tensor(x, max_bond=32)
+    assert obj.bond_sizes() == [8, 32, 32, 32, 32, 32, 8]
+    assert obj.number_elements_in_MPS() == 36992  # SURVEY 8 table
+    rec = obj.to_tensor(as_torch=True)
+    err = _projection_checks(x, obj, rec)
+    assert err < 1e-2
+    # re-encoding the rank-32 reconstruction changes nothing (idempotence of the truncation)
+    again = NDMPS.from_tensor(rec, max_bond=32).to_tensor(as_torch=True)
+    assert float((again - rec).norm() / rec.norm()) <= 1e-5
+    # a larger bond cap can only reduce the error
+    err64 = _projection_checks(x, *(lambda o: (o, o.to_tensor(as_torch=True)))(NDMPS.from_tensor(x, max_bond=64)))
+    assert err64 <= err
+
+
+def test_config3_512_cubed_dct_chi64_properties():
+    """BASELINE configs[2]: 512^3 fp32, DCT mode, chi = 64 (HBM-bound reshape path)."""
+    g = torch.Generator(device=DEV).manual_seed(2025)
+    z = torch.linspace(0, 1, 512, device=DEV)
+    x = (torch.sin(6.0 * z)[:, None, None] * torch.cos(4.0 * z)[None, :, None] * (1.0 + z)[None, None, :]
+         + 0.3 * torch.exp(-((z[:, None, None] - 0.4) ** 2 + (z[None, :, None] - 0.6) ** 2 + (z[None, None, :] - 0.5) ** 2) / 0.02)
+         + 0.01 * torch.randn((512, 512, 512), device=DEV, generator=g)).float()
+    x -= x.min()
+    x /= x.max()
+    obj = NDMPS.from_tensor(x, mode="DCT", max_bond=64)
+    assert obj.bond_sizes() == [8, 64, 64, 64, 64, 64, 64, 8]
+    assert obj.number_elements_in_MPS() == 172160  # SURVEY 8 table
+    rec = obj.to_tensor(as_torch=True)
+    assert rec.shape == x.shape
+    err = _projection_checks(x, obj, rec)  # the orthonormal DCT keeps the projection identities
+    assert err < 2e-3
+    del rec, obj
+    torch.cuda.empty_cache()
+
+
+def test_config4_batch_of_128_cubed_chi32_matches_oracle_on_samples():
+    """BASELINE configs[3] (one rank's shard): 8 independent 128^3 volumes, chi = 32, encoded in
+    lockstep; two of them are checked against the oracle, all of them through properties."""
+    vols = [synthetic_mri((128, 128, 128), seed=2025 + i) for i in range(8)]
+    objs = NDMPS.from_tensors(vols, max_bond=32)
+    for i, (v, o) in enumerate(zip(vols, objs)):
+        assert o.bond_sizes() == [8, 32, 32, 32, 32, 8] and o.number_elements_in_MPS() == 28800
+        rec = o.to_tensor(as_torch=True)
+        _projection_checks(torch.from_numpy(v).to(DEV), o, rec)
+        if i in (0, 5):
+            ref = OracleNDMPS.from_tensor(v, max_bond=32)
+            rr = ref.to_tensor()
+            assert np.linalg.norm(rec.cpu().numpy() - rr) / np.linalg.norm(rr) <= 2e-5
+            assert _ssim_gap(v, rec.cpu().numpy(), rr) <= 1e-5
