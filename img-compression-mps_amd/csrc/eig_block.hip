@@ -55,6 +55,7 @@ struct BatchDesc {
   int pad;
   double tol_conv;
   double tol_rot;
+  double rel_tol;      // convergence threshold relative to max |diag| (input)
 };
 
 struct Work {          // common padded working set; per-matrix strides np*np and (nb/2)*PS*PS
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256) blk_scale_kernel(BatchDesc* __restrict__ 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    d.tol_conv = 1e-15 * red[0];
+    d.tol_conv = d.rel_tol * red[0];
     d.tol_rot = 1e-19 * red[0];
     d.rotated[0] = 0;
     d.rotated[1] = 0;
@@ -695,10 +696,12 @@ extern "C" int64_t ndmps_syevj_batched_workspace_bytes(int64_t n_max, int batch)
 
 extern "C" int64_t ndmps_syevj_workspace_bytes(int64_t n) { return ndmps_syevj_batched_workspace_bytes(n, 1); }
 
-extern "C" int ndmps_syevj_batched_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n, double* d_V,
-                                       int64_t stride_V, double* d_w, int64_t stride_w, void* d_ws,
-                                       int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream) {
+extern "C" int ndmps_syevj_batched_tol_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n,
+                                           double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
+                                           double rel_tol, void* d_ws, int64_t ws_bytes, int* h_sweeps,
+                                           ndmps_stream_t stream) {
   NDMPS_REQUIRE(batch >= 1 && batch <= 4096, "batch=%d outside [1, 4096]", batch);
+  NDMPS_REQUIRE(rel_tol >= 1e-16 && rel_tol <= 1e-6, "rel_tol=%g outside [1e-16, 1e-6]", rel_tol);
   NDMPS_REQUIRE(d_G && d_V && d_w && h_n, "NULL eigen operand");
   std::vector<BatchDesc> desc(batch);
   int64_t n_max = 0;
@@ -712,8 +715,16 @@ extern "C" int ndmps_syevj_batched_f64(int batch, double* d_G, int64_t stride_G,
     desc[b].V_out = d_V + b * stride_V;
     desc[b].w_out = d_w + b * stride_w;
     desc[b].n = (int)h_n[b];
+    desc[b].rel_tol = rel_tol;
   }
   return solve_batched(batch, desc, n_max, d_ws, ws_bytes, h_sweeps, (hipStream_t)stream);
+}
+
+extern "C" int ndmps_syevj_batched_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n, double* d_V,
+                                       int64_t stride_V, double* d_w, int64_t stride_w, void* d_ws,
+                                       int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream) {
+  return ndmps_syevj_batched_tol_f64(batch, d_G, stride_G, h_n, d_V, stride_V, d_w, stride_w, 1e-15, d_ws,
+                                     ws_bytes, h_sweeps, stream);
 }
 
 extern "C" int ndmps_syevj_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,

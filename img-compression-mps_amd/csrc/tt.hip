@@ -15,6 +15,7 @@
 // below kCutoffFloor * sigma_0 are representation noise of fp32 input and are dropped even
 // when the caller's cutoff is smaller (the reference's 1e-10 presumes fp64 data).
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -24,6 +25,20 @@
 namespace {
 
 constexpr double kCutoffFloor = 1e-6;
+// Jacobi convergence threshold of the sweep's eigenproblems, relative to the largest eigenvalue.
+// The data is fp32: off-diagonal couplings below 1e-13 lambda_0 move the kept subspace by less than
+// fp32 rounding even inside a noise-floor cluster (gaps ~1e-9 lambda_0); override for experiments with
+// NDMPS_SWEEP_EIG_TOL.
+constexpr double kSweepEigTol = 1e-13;
+
+inline double sweep_eig_tol() {
+  const char* e = getenv("NDMPS_SWEEP_EIG_TOL");
+  if (e) {
+    const double v = atof(e);
+    if (v >= 1e-16 && v <= 1e-6) return v;
+  }
+  return kSweepEigTol;
+}
 
 using ndmps::arena_bytes;
 using ndmps::Arena;
@@ -256,8 +271,8 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
     }
     // ---- one batched eigen-solve for the site
     int sweeps = 0;
-    NDMPS_TRY(ndmps_syevj_batched_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, ev_ws, ev_ws_bytes,
-                                      &sweeps, s));
+    NDMPS_TRY(ndmps_syevj_batched_tol_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(),
+                                          ev_ws, ev_ws_bytes, &sweeps, s));
     NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
                                    hipMemcpyDeviceToHost, s));
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));

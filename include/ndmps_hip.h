@@ -129,6 +129,12 @@ int64_t ndmps_syevj_batched_workspace_bytes(int64_t n_max, int batch);
 int ndmps_syevj_batched_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n, double* d_V,
                             int64_t stride_V, double* d_w, int64_t stride_w, void* d_ws,
                             int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
+/* same with an explicit convergence threshold: a sweep with no |a_pq| above rel_tol * max|a_ii|
+ * ends the iteration (ndmps_syevj_*_f64 use 1e-15; the fp32 sweep uses kSweepEigTol, tt.hip) */
+int ndmps_syevj_batched_tol_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n,
+                                double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
+                                double rel_tol, void* d_ws, int64_t ws_bytes, int* h_sweeps,
+                                ndmps_stream_t stream);
 /* same contract, scalar-parallel Jacobi (one launch per rotation step); kept as the
  * cross-check of the block solver above */
 int64_t ndmps_syevj_simple_workspace_bytes(int64_t n);
