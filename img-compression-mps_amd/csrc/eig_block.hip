@@ -41,7 +41,7 @@ constexpr int BS = 16;       // block size
 constexpr int PS = 2 * BS;   // pair size (LDS sub-problem edge)
 constexpr int LD = PS + 1;   // padded LDS row
 constexpr int kMaxSweepsBlock = 40;
-constexpr int kTilesPerWg = 4;  // column pairs streamed by one apply workgroup
+constexpr int kTilesPerWg = 8;  // column pairs streamed by one apply workgroup
 
 // one entry per matrix of the batch (device array); blockIdx.y selects it in every kernel
 struct BatchDesc {
@@ -345,8 +345,21 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       QA[row][BS + c0] = a1.x;
       QA[row][BS + c0 + 1] = a1.y;
     }
+    // software pipeline: the operands of tile j+1 are fetched into registers while tile j is in LDS
+    double2 t0, t1, q0, q1;
+    auto fetch = [&](int pb_) {
+      int lo_b_, hi_b_;
+      pair_blocks(pb_, t, nb, lo_b_, hi_b_);
+      if (is_g && pa == pb_) return;  // diagonal tile: nothing to multiply
+      t0 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)lo_b_ * BS + c0);
+      t1 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)hi_b_ * BS + c0);
+      q0 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb_ * PS * PS + row * PS + c0);
+      q1 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb_ * PS * PS + row * PS + BS + c0);
+    };
+    const int pb_first = chunk * kTilesPerWg;
+    if (pb_first < half) fetch(pb_first);
     for (int j = 0; j < kTilesPerWg; ++j) {
-      const int pb = chunk * kTilesPerWg + j;
+      const int pb = pb_first + j;
       if (pb >= half) break;
       int lo_b, hi_b;
       pair_blocks(pb, t, nb, lo_b, hi_b);
@@ -356,12 +369,9 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
         const double* dsrc = Dcur + (int64_t)pa * PS * PS + row * PS;
         *reinterpret_cast<double2*>(o0) = *reinterpret_cast<const double2*>(dsrc + c0);
         *reinterpret_cast<double2*>(o1) = *reinterpret_cast<const double2*>(dsrc + BS + c0);
+        if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);
         continue;
       }
-      const double2 t0 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)lo_b * BS + c0);
-      const double2 t1 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)hi_b * BS + c0);
-      const double2 q0 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb * PS * PS + row * PS + c0);
-      const double2 q1 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb * PS * PS + row * PS + BS + c0);
       __syncthreads();  // the previous tile's readers of T / QB / X are done
       T[row][c0] = t0.x;
       T[row][c0 + 1] = t0.y;
@@ -371,6 +381,7 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       QB[row][c0 + 1] = q0.y;
       QB[row][BS + c0] = q1.x;
       QB[row][BS + c0 + 1] = q1.y;
+      if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);  // in flight during the two GEMMs
       __syncthreads();
       lds_gemm32<false>(T, QB, X, wave, lane);  // X = T Q_B
       __syncthreads();
@@ -387,6 +398,9 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
   }
 
   // ==================================================================== diag role (step t_next)
+  // the diag workgroups are the serial chain of the launch: let their waves win issue arbitration
+  // against co-resident apply waves
+  __builtin_amdgcn_s_setprio(3);
   double* Qnext = w.Q[q_cur ^ 1] + qoff;
   double* Dnext = w.D[q_cur ^ 1] + qoff;
   int lo, hi;

@@ -639,3 +639,29 @@ def test_config4_batch_of_128_cubed_chi32_matches_oracle_on_samples():
             rr = ref.to_tensor()
             assert np.linalg.norm(rec.cpu().numpy() - rr) / np.linalg.norm(rr) <= 2e-5
             assert _ssim_gap(v, rec.cpu().numpy(), rr) <= 1e-5
+
+
+def test_config5_shape_4d_fmri_chi128_fp32_properties():
+    """BASELINE configs[4] geometry (128x128x64x256, site dims 64,32,16,16,16,32, chi = 128) in fp32
+    storage (bf16 storage is not built this round): eigenproblems up to 2048 x 2048."""
+    g = torch.Generator(device=DEV).manual_seed(7)
+    ax = [torch.linspace(-1, 1, n, device=DEV) for n in (128, 128, 64)]
+    vol = torch.zeros((128, 128, 64), device=DEV)
+    for c, w_, a in ((0.2, 0.3, 1.0), (-0.4, 0.15, 0.7), (0.5, 0.5, 0.4)):
+        vol += a * (torch.exp(-0.5 * ((ax[0] - c) / w_) ** 2)[:, None, None]
+                    * torch.exp(-0.5 * ((ax[1] + c) / w_) ** 2)[None, :, None]
+                    * torch.exp(-0.5 * (ax[2] / (2 * w_)) ** 2)[None, None, :])
+    tt = torch.linspace(0, 1, 256, device=DEV)
+    x = vol[..., None] * (1.0 + 0.25 * torch.sin(2 * math.pi * 2.0 * tt))
+    x = (x + 0.01 * torch.randn(x.shape, device=DEV, generator=g)).float()
+    x -= x.min()
+    x /= x.max()
+    assert list(hc.site_dims((128, 128, 64, 256))) == [64, 32, 16, 16, 16, 32]
+    obj = NDMPS.from_tensor(x, max_bond=128)
+    assert obj.bond_sizes() == [64, 128, 128, 128, 32]
+    assert obj.number_elements_in_MPS() == 857088  # SURVEY 8 table
+    rec = obj.to_tensor(as_torch=True)
+    err = _projection_checks(x, obj, rec)
+    assert err < 5e-3
+    del rec, obj, x
+    torch.cuda.empty_cache()
