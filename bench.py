@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--mode", default="Std", choices=["Std", "DCT"])
     ap.add_argument("--batch", type=int, default=8, help="independent volumes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-single", action="store_true", help="profiling aid: no single-volume phase")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses N ranks on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
@@ -118,13 +119,15 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # single-volume latency (batch of one), same kernels; not part of `value`
-    single_step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    single_ms = float("nan")
+    if not args.skip_single:
         single_step()
-    torch.cuda.synchronize()
-    single_ms = (time.perf_counter() - t0) / 3 * 1e3
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            single_step()
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t0) / 3 * 1e3
 
     # roofline of the reshape stage (the HBM-bound kernel north_star names): the tiled
     # encode_permute kernel reads 4 B and writes 4 B per voxel, one launch per step.

@@ -60,9 +60,18 @@ struct Mfma<double> {
 
 // ----------------------------------------------------------------------------------
 // Generic tiled GEMM.  256 threads = 4 waves laid out WAVES_M x WAVES_N over a BM x BN
-// block tile; BK-deep k-tiles staged through LDS (k-major for both operands).
+// block tile; BK-deep k-tiles staged through LDS (k-major for both operands).  The next
+// k-tile is fetched into registers while the current one is consumed (one LDS buffer, two
+// barriers per k-tile).  VEC: every operand row is a multiple of 4 elements and 16-byte
+// (32-byte for fp64) aligned, so a thread moves 4 consecutive elements per global access;
+// otherwise element-wise guarded loads (any shape, any leading dimension).
 // ----------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+template <typename T>
+struct alignas(sizeof(T) * 4) Quad {
+  T v[4];
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool VEC>
 __global__ void __launch_bounds__(256)
 gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
             const T* __restrict__ B, int64_t ldb, T* __restrict__ C, int64_t ldc) {
@@ -72,8 +81,10 @@ gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t ld
   constexpr int TM = BM / (WAVES_M * MT);
   constexpr int TN = BN / (WAVES_N * MT);
   constexpr int PAD = 4;
+  constexpr int A_PER = BM * BK / 256, B_PER = BN * BK / 256;  // elements per thread and k-tile
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   static_assert(TM >= 1 && TN >= 1, "tile too small");
+  constexpr bool VA = VEC && A_PER % 4 == 0, VB = VEC && B_PER % 4 == 0;  // per-operand vector staging
 
   __shared__ T As[BK][BM + PAD];
   __shared__ T Bs[BK][BN + PAD];
@@ -94,39 +105,136 @@ gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t ld
 #pragma unroll
       for (int r = 0; r < MF::NACC; ++r) acc[i][j][r] = (T)0;
 
-  for (int64_t k0 = 0; k0 < K; k0 += BK) {
-    // ---- stage A tile: As[k][m] = op(A)[m0+m][k0+k]
-    if (TA) {  // stored (K, M): contiguous along m
-      for (int e = tid; e < BK * BM; e += 256) {
-        const int k = e / BM, m = e % BM;
-        const int64_t gk = k0 + k, gm = m0 + m;
-        As[k][m] = (gk < K && gm < M) ? A[gk * lda + gm] : (T)0;
-      }
-    } else {  // stored (M, K): contiguous along k
-      for (int e = tid; e < BK * BM; e += 256) {
-        const int m = e / BK, k = e % BK;
-        const int64_t gk = k0 + k, gm = m0 + m;
-        As[k][m] = (gk < K && gm < M) ? A[gm * lda + gk] : (T)0;
-      }
-    }
-    // ---- stage B tile: Bs[k][n] = op(B)[k0+k][n0+n]
-    if (TB) {  // stored (N, K): contiguous along k
-      for (int e = tid; e < BK * BN; e += 256) {
-        const int n = e / BK, k = e % BK;
-        const int64_t gk = k0 + k, gn = n0 + n;
-        Bs[k][n] = (gk < K && gn < N) ? B[gn * ldb + gk] : (T)0;
-      }
-    } else {  // stored (K, N): contiguous along n
-      for (int e = tid; e < BK * BN; e += 256) {
-        const int k = e / BN, n = e % BN;
-        const int64_t gk = k0 + k, gn = n0 + n;
-        Bs[k][n] = (gk < K && gn < N) ? B[gk * ldb + gn] : (T)0;
-      }
-    }
-    __syncthreads();
+  T ra[A_PER], rb[B_PER];
 
-    const int fi = MF::frag_idx(lane);
-    const int fk = MF::frag_k(lane);
+  // op(A)[m][k]: stored (M, K) unless TA (then (K, M)).  contiguous axis: k unless TA (then m)
+  auto fetch_a = [&](int64_t k0) {
+    if (VA) {
+#pragma unroll
+      for (int i = 0; i < A_PER / 4; ++i) {
+        const int e = tid + 256 * i;  // quad index
+        Quad<T> q;
+        q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
+        if (TA) {
+          const int k = e / (BM / 4), m = (e % (BM / 4)) * 4;
+          if (k0 + k < K && m0 + m < M) q = *reinterpret_cast<const Quad<T>*>(A + (k0 + k) * lda + m0 + m);
+        } else {
+          const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
+          if (k0 + k < K && m0 + m < M) q = *reinterpret_cast<const Quad<T>*>(A + (m0 + m) * lda + k0 + k);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[4 * i + j] = q.v[j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        const int e = tid + 256 * i;
+        int m, k;
+        if (TA) {
+          k = e / BM;
+          m = e % BM;
+        } else {
+          m = e / BK;
+          k = e % BK;
+        }
+        const int64_t gk = k0 + k, gm = m0 + m;
+        ra[i] = (gk < K && gm < M) ? (TA ? A[gk * lda + gm] : A[gm * lda + gk]) : (T)0;
+      }
+    }
+  };
+  auto fetch_b = [&](int64_t k0) {
+    if (VB) {
+#pragma unroll
+      for (int i = 0; i < B_PER / 4; ++i) {
+        const int e = tid + 256 * i;
+        Quad<T> q;
+        q.v[0] = q.v[1] = q.v[2] = q.v[3] = (T)0;
+        if (TB) {
+          const int n = e / (BK / 4), k = (e % (BK / 4)) * 4;
+          if (k0 + k < K && n0 + n < N) q = *reinterpret_cast<const Quad<T>*>(B + (n0 + n) * ldb + k0 + k);
+        } else {
+          const int k = e / (BN / 4), n = (e % (BN / 4)) * 4;
+          if (k0 + k < K && n0 + n < N) q = *reinterpret_cast<const Quad<T>*>(B + (k0 + k) * ldb + n0 + n);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[4 * i + j] = q.v[j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int e = tid + 256 * i;
+        int n, k;
+        if (TB) {
+          n = e / BK;
+          k = e % BK;
+        } else {
+          k = e / BN;
+          n = e % BN;
+        }
+        const int64_t gk = k0 + k, gn = n0 + n;
+        rb[i] = (gk < K && gn < N) ? (TB ? B[gn * ldb + gk] : B[gk * ldb + gn]) : (T)0;
+      }
+    }
+  };
+  auto commit = [&]() {
+    if (VA) {
+#pragma unroll
+      for (int i = 0; i < A_PER / 4; ++i) {
+        const int e = tid + 256 * i;
+        if (TA) {
+          const int k = e / (BM / 4), m = (e % (BM / 4)) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) As[k][m + j] = ra[4 * i + j];
+        } else {
+          const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) As[k + j][m] = ra[4 * i + j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        const int e = tid + 256 * i;
+        if (TA) As[e / BM][e % BM] = ra[i];
+        else As[e % BK][e / BK] = ra[i];
+      }
+    }
+    if (VB) {
+#pragma unroll
+      for (int i = 0; i < B_PER / 4; ++i) {
+        const int e = tid + 256 * i;
+        if (TB) {
+          const int n = e / (BK / 4), k = (e % (BK / 4)) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[k + j][n] = rb[4 * i + j];
+        } else {
+          const int k = e / (BN / 4), n = (e % (BN / 4)) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[k][n + j] = rb[4 * i + j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int e = tid + 256 * i;
+        if (TB) Bs[e % BK][e / BK] = rb[i];
+        else Bs[e / BN][e % BN] = rb[i];
+      }
+    }
+  };
+
+  fetch_a(0);
+  fetch_b(0);
+  const int fi = MF::frag_idx(lane);
+  const int fk = MF::frag_k(lane);
+  for (int64_t k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();  // previous k-tile fully consumed
+    commit();
+    __syncthreads();
+    if (k0 + BK < K) {  // next k-tile in flight under the MFMAs
+      fetch_a(k0 + BK);
+      fetch_b(k0 + BK);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += MF::KS) {
       T a[TM], b[TN];
@@ -139,7 +247,6 @@ gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t ld
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], b[j], acc[i][j]);
     }
-    __syncthreads();
   }
 
   // ---- epilogue
@@ -161,13 +268,23 @@ int launch_gemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const T
                 const T* B, int64_t ldb, T* C, int64_t ldc, hipStream_t stream) {
   dim3 grid((unsigned)ndmps::ceil_div(m, BM), (unsigned)ndmps::ceil_div(n, BN));
   dim3 block(256);
-#define NDMPS_GEMM_LAUNCH(TA_, TB_)                                                             \
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TA_, TB_>), grid, block, 0, stream, \
+  // vector path: whole quads are either inside or outside every bound, and 4-element aligned
+  const uintptr_t al = sizeof(T) * 4;
+  const bool vec = lda % 4 == 0 && ldb % 4 == 0 && k % 4 == 0 && (!transA || m % 4 == 0) &&
+                   (transB || n % 4 == 0) && (uintptr_t)A % al == 0 && (uintptr_t)B % al == 0;
+#define NDMPS_GEMM_LAUNCH(TA_, TB_, V_)                                                                 \
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TA_, TB_, V_>), grid, block, 0, stream, \
                      m, n, k, A, lda, B, ldb, C, ldc)
-  if (transA && transB) NDMPS_GEMM_LAUNCH(true, true);
-  else if (transA) NDMPS_GEMM_LAUNCH(true, false);
-  else if (transB) NDMPS_GEMM_LAUNCH(false, true);
-  else NDMPS_GEMM_LAUNCH(false, false);
+#define NDMPS_GEMM_TRANS(V_)                                     \
+  do {                                                           \
+    if (transA && transB) NDMPS_GEMM_LAUNCH(true, true, V_);     \
+    else if (transA) NDMPS_GEMM_LAUNCH(true, false, V_);         \
+    else if (transB) NDMPS_GEMM_LAUNCH(false, true, V_);         \
+    else NDMPS_GEMM_LAUNCH(false, false, V_);                    \
+  } while (0)
+  if (vec) NDMPS_GEMM_TRANS(true);
+  else NDMPS_GEMM_TRANS(false);
+#undef NDMPS_GEMM_TRANS
 #undef NDMPS_GEMM_LAUNCH
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
