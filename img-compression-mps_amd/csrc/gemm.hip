@@ -445,13 +445,19 @@ int launch_tile_reduce(double* partial, int n_slabs, int n_tiles_1d, int n_tiles
 // waves (2 x 2, 64 x 64 each, 16 f64 MFMA accumulators) consume the current one.
 // LDS rows are padded by 16 floats: a fragment read (4 rows x 16 columns) is conflict-free.
 // ----------------------------------------------------------------------------------
-constexpr int GW_TS = 128;   // tile edge
 constexpr int GW_KB = 32;    // rows per staged chunk
-constexpr int GW_LD = GW_TS + 16;
 
+// GW_TS: tile edge, 128 (n >= 128) or 64 (64 <= n < 128); each of the 2 x 2 waves owns a
+// (GW_TS/2)^2 sub-tile = (GW_TS/32)^2 MFMA accumulators
+template <int GW_TS>
 __global__ void __launch_bounds__(256)
 gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
                  double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab, int vec_ok) {
+  constexpr int GW_LD = GW_TS + 16;
+  constexpr int NT = GW_TS / 32;       // MFMA tiles per wave and direction
+  constexpr int SUB = GW_TS / 2;       // wave sub-tile edge
+  constexpr int QPR = GW_TS / 4;       // float4 per staged row
+  constexpr int VPT = GW_KB * QPR / 256;  // float4 per thread and panel
   __shared__ float Ai[GW_KB][GW_LD];
   __shared__ float Aj[GW_KB][GW_LD];
 
@@ -470,19 +476,19 @@ gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane >> 4, lc = lane & 15;
 
-  f64x4 acc[4][4];
+  f64x4 acc[NT][NT];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-  // staging map: 32 rows x 32 float4 per panel = 1024 float4, 4 per thread
-  float4 pi[4], pj[4];
+  // staging map: GW_KB rows x QPR float4 per panel, VPT per thread
+  float4 pi[VPT], pj[VPT];
   auto fetch = [&](int64_t r0) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < VPT; ++v) {
       const int e = tid + 256 * v;
-      const int rr = e >> 5, c4 = (e & 31) * 4;
+      const int rr = e / QPR, c4 = (e % QPR) * 4;
       const int64_t row = r0 + rr;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
       if (row < r_end) {
@@ -510,9 +516,9 @@ gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < VPT; ++v) {
       const int e = tid + 256 * v;
-      const int rr = e >> 5, c4 = (e & 31) * 4;
+      const int rr = e / QPR, c4 = (e % QPR) * 4;
       *reinterpret_cast<float4*>(&Ai[rr][c4]) = pi[v];
       if (!diag) *reinterpret_cast<float4*>(&Aj[rr][c4]) = pj[v];
     }
@@ -527,28 +533,28 @@ gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
     const float (*Bj)[GW_LD] = diag ? Ai : Aj;
 #pragma unroll
     for (int k0 = 0; k0 < GW_KB; k0 += 4) {
-      double av[4], bv[4];
+      double av[NT], bv[NT];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        av[a] = (double)Ai[k0 + lr][wr * 64 + 16 * a + lc];
-        bv[a] = (double)Bj[k0 + lr][wc * 64 + 16 * a + lc];
+      for (int a = 0; a < NT; ++a) {
+        av[a] = (double)Ai[k0 + lr][wr * SUB + 16 * a + lc];
+        bv[a] = (double)Bj[k0 + lr][wc * SUB + 16 * a + lc];
       }
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
   }
 
   double* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GW_TS * GW_TS);
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int rr = wr * 64 + 16 * a + lr + 4 * reg, cc = wc * 64 + 16 * b + lc;
+        const int rr = wr * SUB + 16 * a + lr + 4 * reg, cc = wc * SUB + 16 * b + lc;
         out[rr * GW_TS + cc] = acc[a][b][reg];
       }
 }
@@ -670,9 +676,12 @@ extern "C" int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t
 }
 
 // geometry of the 128-wide path: ~2 workgroups per CU, slabs a multiple of the 32-row chunk
+inline int gram_wide_tile(int64_t n) { return n >= 128 ? 128 : 64; }
+
 GramGeom gram_wide_geometry(int64_t m, int64_t n) {
   GramGeom g;
-  g.T = 8;
+  const int GW_TS = gram_wide_tile(n);
+  g.T = GW_TS / 16;
   g.tiles_1d = (int)ndmps::ceil_div(n, GW_TS);
   g.n_tiles = g.tiles_1d * (g.tiles_1d + 1) / 2;
   const int64_t want = std::max<int64_t>(1, (2 * ndmps::kNumCU) / g.n_tiles);
@@ -681,7 +690,7 @@ GramGeom gram_wide_geometry(int64_t m, int64_t n) {
   return g;
 }
 
-inline bool gram_use_wide(int64_t m, int64_t n) { return n >= 128 && m >= 256; }
+inline bool gram_use_wide(int64_t m, int64_t n) { return n >= 64 && m >= 256; }
 inline bool gram_use_small(int64_t n) { return n <= 8; }
 
 extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
@@ -689,8 +698,8 @@ extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
   if (gram_use_small(n)) return (int64_t)kGramSmallBlocks * 36 * 8 + 256;
   if (gram_use_wide(m, n)) {
     GramGeom g = gram_wide_geometry(m, n);
-    return (int64_t)(g.n_slabs + g.n_slabs / kReduceGroup + 2) * g.n_tiles * GW_TS * GW_TS *
-               (int64_t)sizeof(double) + 256;
+    const int64_t ts = gram_wide_tile(n);
+    return (int64_t)(g.n_slabs + g.n_slabs / kReduceGroup + 2) * g.n_tiles * ts * ts * (int64_t)sizeof(double) + 256;
   }
   GramGeom g = gram_geometry(m, n);
   const int ts = 16 * g.T;
@@ -721,10 +730,16 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
   if (gram_use_wide(m, n)) {
     GramGeom gw = gram_wide_geometry(m, n);
     NDMPS_REQUIRE(gw.n_slabs < 65536, "Gram slab count %d exceeds grid.y", gw.n_slabs);
-    hipLaunchKernelGGL(gram_wide_kernel, dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda, partial,
-                       gw.tiles_1d, gw.rows_per_slab, vec_ok);
+    if (gram_wide_tile(n) == 128) {
+      hipLaunchKernelGGL(gram_wide_kernel<128>, dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
+                         partial, gw.tiles_1d, gw.rows_per_slab, vec_ok);
+      NDMPS_LAUNCH_CHECK();
+      return launch_tile_reduce<128>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
+    }
+    hipLaunchKernelGGL(gram_wide_kernel<64>, dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
+                       partial, gw.tiles_1d, gw.rows_per_slab, vec_ok);
     NDMPS_LAUNCH_CHECK();
-    return launch_tile_reduce<GW_TS>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
+    return launch_tile_reduce<64>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
   }
   GramGeom g = gram_geometry(m, n);
   NDMPS_REQUIRE(g.n_slabs < 65536, "Gram slab count %d exceeds grid.y", g.n_slabs);
