@@ -107,12 +107,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // power of two (one rsqrt, one rcp), then c = rsqrt(1 + t^2), s = t c.
 __device__ __forceinline__ void rotation64(double app, double aqq, double apq, double tol_rot, double& c,
                                            double& s, double& t) {
-  if (!(fabs(apq) > tol_rot)) {
-    c = 1.0;
-    s = 0.0;
-    t = 0.0;
-    return;
-  }
+  // branch-free: computed for every pair (NaNs from a 0/0 pair are discarded by the selects), so
+  // the compiler can overlap the chain with the independent LDS traffic around it
   const double a = aqq - app, b = 2.0 * apq;
   int e;
   (void)frexp(fmax(fabs(a), fabs(b)), &e);
@@ -120,9 +116,12 @@ __device__ __forceinline__ void rotation64(double app, double aqq, double apq, d
   const double h2 = fma(as, as, bs * bs);
   const double h = h2 * fast_rsqrt<1>(h2);
   const double mag = bs * fast_rcp<1>(as + h);
-  t = ((a < 0.0) != (b < 0.0)) ? -mag : mag;
-  c = fast_rsqrt<2>(fma(t, t, 1.0));
-  s = t * c;
+  const double tt = ((a < 0.0) != (b < 0.0)) ? -mag : mag;
+  const double cc = fast_rsqrt<2>(fma(tt, tt, 1.0));
+  const bool act = fabs(apq) > tol_rot;
+  t = act ? tt : 0.0;
+  c = act ? cc : 1.0;
+  s = act ? tt * cc : 0.0;
 }
 
 // ---------------------------------------------------------------------------- setup
@@ -453,8 +452,21 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
   const int K = tid >> 4, M = tid & 15;
   const int n_inner = full_next ? PS - 1 : BS;
   const int max_rounds = solve ? kMaxSweepsBlock : 1;
+  const int r0 = 2 * K, r1 = 2 * K + 1;  // this thread's (static) rows of Q
   bool converged = false;
   int cur = 0;
+  // the Q update of an inner step touches only this thread's own entries, so it is deferred by one
+  // step and overlaps the next step's rotation chain
+  bool pending = false;
+  double pc = 1.0, ps = 0.0;
+  int pcol_r = 0, pcol_s = 0;
+  auto flush_q = [&]() {
+    const double q0r = Q[r0][pcol_r], q0s = Q[r0][pcol_s], q1r = Q[r1][pcol_r], q1s = Q[r1][pcol_s];
+    Q[r0][pcol_r] = pc * q0r - ps * q0s;
+    Q[r0][pcol_s] = ps * q0r + pc * q0s;
+    Q[r1][pcol_r] = pc * q1r - ps * q1s;
+    Q[r1][pcol_s] = ps * q1r + pc * q1s;
+  };
   for (int round = 0; round < max_rounds; ++round) {
     int before = 0;
     if (solve) {
@@ -476,6 +488,8 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       }
       // own (column) rotation: pair M; the row rotation of pair K lives in lane K of this wave
       const double arr = S[r][r], ass = S[s_][s_], ars = S[r][s_];
+      const double gpr = S[p][r], gps = S[p][s_], gqr = S[q][r], gqs = S[q][s_];
+      if (pending) flush_q();
       double c2, s2, t2;
       rotation64(arr, ass, ars, tol_rot, c2, s2, t2);
       const double c1 = __shfl(c2, K, 64), s1 = __shfl(s2, K, 64);
@@ -483,7 +497,6 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
         const unsigned long long m = __ballot(lane < BS && fabs(ars) > tol_conv);
         if (lane == 0) cnt += __popcll(m);
       }
-      const double gpr = S[p][r], gps = S[p][s_], gqr = S[q][r], gqs = S[q][s_];
       const double xpr = c2 * gpr - s2 * gps, xps = s2 * gpr + c2 * gps;
       const double xqr = c2 * gqr - s2 * gqs, xqs = s2 * gqr + c2 * gqs;
       double ypr = c1 * xpr - s1 * xqr, yps = c1 * xps - s1 * xqs;
@@ -496,13 +509,11 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       Sn[p][s_] = yps;
       Sn[q][r] = yqr;
       Sn[q][s_] = yqs;
-      // Q <- Q J: rows 2K, 2K+1 (static), columns (r, s_); own entries only, in place
-      const int r0 = 2 * K, r1 = 2 * K + 1;
-      const double q0r = Q[r0][r], q0s = Q[r0][s_], q1r = Q[r1][r], q1s = Q[r1][s_];
-      Q[r0][r] = c2 * q0r - s2 * q0s;
-      Q[r0][s_] = s2 * q0r + c2 * q0s;
-      Q[r1][r] = c2 * q1r - s2 * q1s;
-      Q[r1][s_] = s2 * q1r + c2 * q1s;
+      pending = true;
+      pc = c2;
+      ps = s2;
+      pcol_r = r;
+      pcol_s = s_;
       __syncthreads();
       cur ^= 1;
     }
@@ -511,6 +522,8 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       break;
     }
   }
+  if (pending) flush_q();
+  __syncthreads();
 
   for (int e = tid; e < PS * PS; e += 256) {
     Dnext[(int64_t)blockIdx.x * PS * PS + e] = (cur ? S1 : S0)[e / PS][e % PS];
