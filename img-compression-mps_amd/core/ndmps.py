@@ -198,6 +198,7 @@ class NDMPS:
             if isinstance(tensor, torch.Tensor):
                 if tensor.dim() == 0:
                     raise ValueError("Shape cannot be empty.")
+                # bf16 / fp16 volumes stay 2 bytes per voxel in HBM until here; arithmetic is fp32
                 x = tensor.detach().to(device=device, dtype=torch.float32, copy=True).contiguous()
             else:
                 arr = np.asarray(tensor)
@@ -351,11 +352,12 @@ class NDMPS:
                 print(f"Compression ratio at {c}: {self.compression_ratio()}")
 
     # ------------------------------------------------------------------ reconstruct
-    def to_tensor(self, as_torch: bool = False):
+    def to_tensor(self, as_torch: bool = False, dtype=None):
         """
         Convert MPS back to tensor format (with optional inverse DCT).
 
-        Returns a NumPy array like the reference; ``as_torch=True`` keeps the result in HBM.
+        Returns a NumPy array like the reference; ``as_torch=True`` keeps the result in HBM and
+        ``dtype`` (e.g. ``torch.bfloat16``) selects its storage type (arithmetic stays fp32).
         """
         torch = _torch()
         lib = _lib.load()
@@ -378,7 +380,9 @@ class NDMPS:
                 out = rec
             elif self.mode != "Std":
                 return None  # ndmps.py:150-153: unknown modes fall through
-        return out if as_torch else out.cpu().numpy()
+        if as_torch:
+            return out if dtype is None else out.to(dtype)
+        return out.cpu().numpy()
 
     # ---------------------------------------------------- quantise / on-disk size
     def compress_to_dtype(self, dtype=np.uint16, replace: bool = False):

@@ -665,3 +665,42 @@ def test_config5_shape_4d_fmri_chi128_fp32_properties():
     assert err < 5e-3
     del rec, obj, x
     torch.cuda.empty_cache()
+
+
+def test_bf16_volume_in_and_out():
+    """bf16 storage at the boundary (BASELINE configs[4] names bf16): the volume is read as bf16,
+    arithmetic is fp32, the reconstruction can be returned as bf16.  Checked against the oracle on
+    the bf16-rounded values; tolerance = bf16 rounding of the output (2^-8 relative)."""
+    x32 = torch.from_numpy(synthetic_mri((32, 32, 16, 24), seed=5)).to(DEV)
+    xb = x32.to(torch.bfloat16)
+    obj = NDMPS.from_tensor(xb, max_bond=20)
+    ref = OracleNDMPS.from_tensor(xb.float().cpu().numpy(), max_bond=20)
+    assert obj.bond_sizes() == ref.bond_sizes()
+    rr = ref.to_tensor()
+    r32 = obj.to_tensor(as_torch=True)
+    assert float((r32.double().cpu() - torch.from_numpy(rr)).norm() / np.linalg.norm(rr)) <= 2e-5
+    rb = obj.to_tensor(as_torch=True, dtype=torch.bfloat16)
+    assert rb.dtype == torch.bfloat16 and rb.shape == xb.shape
+    assert float((rb.float() - r32).abs().max()) <= 2.0 ** -8 * float(r32.abs().max())
+
+
+def test_reference_flow_exact_then_compress_64_and_128_cubed():
+    """The reference's own flow (from_tensor without a bond cap, then cumulative compress(cutoff),
+    evaluation/benchmark.py:176-178) at 64^3 against the oracle, and its exact step at 128^3
+    (bonds 8, 64, 512, 512, 64, 8: 512 x 512 and wide 512 x 4096 unfoldings)."""
+    x = synthetic_mri((64, 64, 64), seed=21)
+    gpu, ref = NDMPS.from_tensor(x), OracleNDMPS.from_tensor(x)
+    assert gpu.bond_sizes() == ref.bond_sizes() == [8, 64, 512, 64, 8]
+    assert np.abs(gpu.to_tensor() - x).max() <= 2e-5
+    for cutoff in (0.01, 0.03, 0.1):
+        gpu.compress(cutoff)
+        ref.compress(cutoff)
+        assert gpu.bond_sizes() == ref.bond_sizes(), cutoff
+        rg, rr = gpu.to_tensor(), ref.to_tensor()
+        assert np.linalg.norm(rg - rr) / np.linalg.norm(rr) <= 5e-5
+        assert _ssim_gap(x, rg, rr) <= 1e-5
+        assert math.isclose(gpu.compression_ratio(), ref.compression_ratio(), rel_tol=1e-12)
+    y = torch.from_numpy(synthetic_mri((128, 128, 128), seed=22)).to(DEV)
+    big = NDMPS.from_tensor(y)
+    assert big.bond_sizes() == [8, 64, 512, 512, 64, 8]
+    assert float((big.to_tensor(as_torch=True) - y).abs().max()) <= 2e-5
