@@ -68,6 +68,10 @@ SIGNATURES = {
     "ndmps_overlap_workspace_bytes": (i64, [C.c_int, p_i64, p_i64, p_i64]),
     "ndmps_overlap_f32": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), p_i64, C.POINTER(vp), p_f64,
                                     vp, i64, vp]),
+    "ndmps_ssim_workspace_bytes": (i64, [C.c_int, p_i64]),
+    "ndmps_ssim_f32": (C.c_int, [vp, vp, C.c_int, p_i64, p_f64, vp, i64, vp]),
+    "ndmps_psnr_workspace_bytes": (i64, []),
+    "ndmps_psnr_f32": (C.c_int, [vp, vp, i64, p_f64, vp, i64, vp]),
     "ndmps_quantize_f32": (C.c_int, [vp, i64, C.c_float, C.c_float, C.c_int, vp, vp]),
     "ndmps_dequantize_f32": (C.c_int, [vp, i64, C.c_float, C.c_float, C.c_int, vp, vp]),
 }

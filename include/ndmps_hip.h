@@ -218,6 +218,19 @@ int ndmps_quantize_f32(const float* d_x, int64_t n, float lo, float hi, int bits
 int ndmps_dequantize_f32(const void* d_q, int64_t n, float lo, float hi, int bits, float* d_x,
                          ndmps_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * Quality metrics on device-resident volumes, semantics of utils/metrics.py:
+ * ndmps_ssim_f32 = compute_ssim_by_dim(a, b) (metrics.py:108-129; 2-D / 3-D / 4-D, uniform window,
+ * per-slice joint data_range, second argument clipped at 0), ndmps_psnr_f32 = compute_psnr(a, b)
+ * (metrics.py:132-146).  fp32 inputs, fp64 arithmetic.  Both synchronise the stream.
+ * --------------------------------------------------------------------------------- */
+int64_t ndmps_ssim_workspace_bytes(int ndim, const int64_t* h_shape);
+int ndmps_ssim_f32(const float* d_a, const float* d_b, int ndim, const int64_t* h_shape,
+                   double* h_out, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+int64_t ndmps_psnr_workspace_bytes(void);
+int ndmps_psnr_f32(const float* d_a, const float* d_b, int64_t n, double* h_out, void* d_ws,
+                   int64_t ws_bytes, ndmps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

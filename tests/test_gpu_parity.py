@@ -704,3 +704,45 @@ def test_reference_flow_exact_then_compress_64_and_128_cubed():
     big = NDMPS.from_tensor(y)
     assert big.bond_sizes() == [8, 64, 512, 512, 64, 8]
     assert float((big.to_tensor(as_torch=True) - y).abs().max()) <= 2e-5
+
+
+# ----------------------------------------------------------------- device-side quality metrics
+def test_device_ssim_psnr_match_oracle_and_reference_fixtures(golden_dir):
+    from imgcompressionmps_amd.utils import metrics as dm
+    from oracle import metrics as om
+
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    for name in ("2d", "3d", "4d", "2d_small"):
+        a32, b32 = g[name + "/a"].astype(np.float32), g[name + "/b"].astype(np.float32)
+        # same fp32 values on both sides: agreement to fp64 rounding
+        want = om.compute_ssim_by_dim(a32.astype(np.float64), b32.astype(np.float64))
+        got = dm.compute_ssim_by_dim(a32, b32)
+        assert abs(got - want) <= 1e-12, (name, got, want)
+        # against the value the reference's own metrics.py produced on the fp64 arrays
+        assert abs(got - float(g[name + "/ssim"])) <= 5e-6
+        wantp = om.compute_psnr(a32.astype(np.float64), b32.astype(np.float64))
+        assert abs(dm.compute_psnr(a32, b32) - wantp) <= 1e-9 * abs(wantp)
+        assert abs(dm.compute_psnr(a32, b32) - float(g[name + "/psnr"])) <= 1e-4
+    x = synthetic_mri((48, 40, 56), seed=9)
+    y = x + 0.03 * np.random.default_rng(1).standard_normal(x.shape).astype(np.float32)  # negative values: clip
+    assert abs(dm.compute_ssim_by_dim(x, y) - om.compute_ssim_by_dim(x.astype(np.float64), y.astype(np.float64))) <= 1e-12
+    assert dm.compute_psnr(x, x) == np.inf
+    with pytest.raises(ValueError):
+        dm.compute_ssim_by_dim(np.zeros(4, dtype=np.float32), np.zeros(4, dtype=np.float32))
+    with pytest.raises(ValueError):
+        dm.compute_ssim_by_dim(np.zeros((2, 9), dtype=np.float32), np.zeros((2, 9), dtype=np.float32))
+
+
+def test_device_ssim_256_cubed_against_oracle_sample():
+    """Full-size SSIM on the device; the oracle checks one axis' worth of slices (host SSIM of a
+    whole 256^3 pair takes ~10 s) plus the full value on a 96^3 crop."""
+    from imgcompressionmps_amd.utils import metrics as dm
+    from oracle import metrics as om
+
+    x = synthetic_mri((256, 256, 256), seed=2025)
+    obj = NDMPS.from_tensor(x, max_bond=16)
+    rec = obj.to_tensor(as_torch=True)
+    full = dm.compute_ssim_by_dim(torch.from_numpy(x).to(DEV), rec)
+    assert 0.3 < full < 1.0
+    xc, rc = x[80:176, 80:176, 80:176], rec[80:176, 80:176, 80:176].cpu().numpy()
+    assert abs(dm.compute_ssim_by_dim(xc, rc) - om.compute_ssim_by_dim(xc.astype(np.float64), rc.astype(np.float64))) <= 1e-12
