@@ -44,8 +44,71 @@ def conv_to_tensors(mps_list: Sequence, as_torch: bool = False):
 
 def compress_list(mps_list: Sequence, cutoff: float, max_bond=None) -> None:
     """benchmark.py:103-118: in-place truncation of every NDMPS of the (local) list."""
+    if cutoff is None:
+        raise ValueError("compression_factors must not be None")
     for m in mps_list:
         m.compress(cutoff, max_bond=max_bond)
+
+
+def benchmark_metric(mps_list, reference_list=None, metric="compression_ratio", dtype=np.uint16):
+    """benchmark.py:121-146, metric by metric, quirks included: ``ssim`` / ``psnr`` are called as
+    f(reconstruction, original) (so the clip at 0 lands on the original and PSNR's peak is the
+    reconstruction's), and ``gzip_ratio`` quantises the cores in place (``replace=True``)."""
+    from ..utils.metrics import compute_overlap, compute_psnr, compute_ssim_by_dim
+
+    metric_fn = {
+        "compression_ratio": lambda mps, _: mps.compression_ratio(),
+        "storage": lambda mps, _: mps.get_storage_space(dtype),
+        "gzip_bytes": lambda mps, _: mps.get_bytesize_on_disk(dtype=dtype),
+        "gzip_ratio": lambda mps, _: mps.compression_ratio_on_disk(dtype=dtype, replace=True),
+        "ssim": lambda mps, ref: compute_ssim_by_dim(mps.to_tensor(as_torch=True), ref),
+        "psnr": lambda mps, ref: compute_psnr(mps.to_tensor(as_torch=True), ref),
+        "bond_dims": lambda mps, _: mps.bond_sizes(),
+        "shape": lambda _, ref: tuple(ref.shape),
+        "fidelity": lambda mps, ref: compute_overlap(mps, ref),
+    }
+    if metric not in metric_fn:
+        raise ValueError(f"Unsupported metric: {metric}")
+    if reference_list and len(reference_list) != len(mps_list):
+        raise IndexError("Length mismatch: reference_list and mps_list must have the same length.")
+    results = []
+    for i, mps in enumerate(mps_list):
+        ref = reference_list[i] if reference_list else None
+        results.append(metric_fn[metric](mps, ref))
+    return results
+
+
+def run_benchmark(mps_list, original_tensors_list, cutoff_list, verbose=True):
+    """benchmark.py:149-194: all metrics before compression and after every (cumulative) cutoff;
+    same result keys, order and array layout ((n_files, 1 + n_cutoffs), ``bond_dims`` left as lists)."""
+    from copy import deepcopy
+
+    original_mps_list = deepcopy(mps_list)
+    metrics = [
+        ("ssim", original_tensors_list),
+        ("compression_ratio", None),
+        ("bond_dims", None),
+        ("psnr", original_tensors_list),
+        ("fidelity", original_mps_list),
+        ("storage", None),
+        ("gzip_bytes", None),
+        ("gzip_ratio", None),
+    ]
+    results = {name: [] for name, _ in metrics}
+    for name, ref in metrics:
+        results[name].append(benchmark_metric(mps_list, ref, metric=name))
+    for i, cutoff in enumerate(cutoff_list):
+        if verbose:
+            print(f"Status: {100 * (i + 1) / len(cutoff_list):.2f}% - Cutoff: {cutoff}")
+        compress_list(mps_list, cutoff)
+        for name, ref in metrics:
+            results[name].append(benchmark_metric(mps_list, ref, metric=name))
+    for key in results:
+        if not results[key] or not results[key][0]:
+            results[key] = []
+        elif key != "bond_dims" and isinstance(results[key][0], (list, np.ndarray)) and np.ndim(results[key][0]) > 0:
+            results[key] = np.array(results[key]).T
+    return results
 
 
 # ------------------------------------------------------------------------ collectives

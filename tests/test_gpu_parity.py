@@ -746,3 +746,47 @@ def test_device_ssim_256_cubed_against_oracle_sample():
     assert 0.3 < full < 1.0
     xc, rc = x[80:176, 80:176, 80:176], rec[80:176, 80:176, 80:176].cpu().numpy()
     assert abs(dm.compute_ssim_by_dim(xc, rc) - om.compute_ssim_by_dim(xc.astype(np.float64), rc.astype(np.float64))) <= 1e-12
+
+
+def test_run_benchmark_matches_an_oracle_driven_loop():
+    """the reference's quality-vs-ratio loop (evaluation/benchmark.py:121-194) over a
+    small list of volumes, device path vs the same loop driven with the oracle classes."""
+    from imgcompressionmps_amd.core import batch
+    from oracle import metrics as om
+
+    vols = [synthetic_mri((32, 32, 32), seed=s) for s in (4, 5)]
+    cutoffs = [0.02, 0.05]
+    gpu_list = batch.conv_to_mps(vols, mode="Std")
+    res = batch.run_benchmark(gpu_list, [torch.from_numpy(v).to(DEV) for v in vols], cutoffs, verbose=False)
+
+    ora = [OracleNDMPS.from_tensor(v) for v in vols]
+    ora0 = copy.deepcopy(ora)
+    want = {k: [] for k in ("ssim", "compression_ratio", "bond_dims", "psnr", "fidelity", "gzip_ratio")}
+
+    def snapshot():
+        want["ssim"].append([om.compute_ssim_by_dim(o.to_tensor(), v.astype(np.float64)) for o, v in zip(ora, vols)])
+        want["compression_ratio"].append([o.compression_ratio() for o in ora])
+        want["bond_dims"].append([o.bond_sizes() for o in ora])
+        want["psnr"].append([om.compute_psnr(o.to_tensor(), v.astype(np.float64)) for o, v in zip(ora, vols)])
+        want["fidelity"].append([om.compute_overlap(o, r) for o, r in zip(ora, ora0)])
+        want["gzip_ratio"].append([o.compression_ratio_on_disk(dtype=np.uint16, replace=True) for o in ora])
+
+    snapshot()
+    for c in cutoffs:
+        for o in ora:
+            o.compress(c)
+        snapshot()
+    assert set(res) == {"ssim", "compression_ratio", "bond_dims", "psnr", "fidelity", "storage", "gzip_bytes", "gzip_ratio"}
+    assert res["ssim"].shape == (2, 3) and res["gzip_ratio"].shape == (2, 3)
+    assert res["bond_dims"] == want["bond_dims"]
+    assert np.allclose(res["compression_ratio"], np.array(want["compression_ratio"]).T, rtol=1e-12)
+    assert np.abs(res["ssim"] - np.array(want["ssim"]).T).max() <= 2e-5
+    # before any truncation the PSNR measures rounding noise: ~140 dB in fp32, ~296 dB in fp64
+    assert np.all(res["psnr"][:, 0] > 120.0)
+    assert np.abs(res["psnr"][:, 1:] - np.array(want["psnr"]).T[:, 1:]).max() <= 5e-3
+    assert np.abs(res["fidelity"] - np.array(want["fidelity"]).T).max() <= 1e-5
+    assert np.abs(res["gzip_ratio"] - np.array(want["gzip_ratio"]).T).max() <= 0.05  # gzip of fp32- vs fp64-derived uint16
+    with pytest.raises(ValueError):
+        batch.benchmark_metric(gpu_list, None, metric="nope")
+    with pytest.raises(IndexError):
+        batch.benchmark_metric(gpu_list, [1], metric="ssim")
