@@ -37,7 +37,10 @@ def parse():
     ap.add_argument("--size", type=int, default=256, help="edge of the cubic volume")
     ap.add_argument("--chi", type=int, default=64)
     ap.add_argument("--mode", default="Std", choices=["Std", "DCT"])
-    ap.add_argument("--batch", type=int, default=8, help="independent volumes per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="independent volumes per GPU per step")
+    ap.add_argument("--groups", type=int, default=4,
+                    help="concurrent groups (host thread + HIP stream each) the batch is cut into; "
+                         "volumes of a group are encoded in lockstep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="profiling aid: no single-volume phase")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -83,10 +86,20 @@ def main():
         xs.append(torch.from_numpy(synthetic_mri(shape, seed=2025 + 1000 * j + rank)).to(device))
     x = xs[0]
 
+    from concurrent.futures import ThreadPoolExecutor
+
+    from imgcompressionmps_amd.core import batch as batch_mod
+
+    pool = ThreadPoolExecutor(max(1, min(args.groups, args.batch)))
+
     def step():
-        objs = NDMPS.from_tensors(xs, mode=args.mode, max_bond=args.chi)
-        recs = [o.to_tensor(as_torch=True) for o in objs]
+        objs, recs = batch_mod.encode_decode_concurrent(xs, groups=args.groups, mode=args.mode,
+                                                         max_bond=args.chi, pool=pool)
         return objs[0], recs[0]
+
+    def group_step(n):  # one lockstep group of n volumes on the current stream
+        objs = NDMPS.from_tensors(xs[:n], mode=args.mode, max_bond=args.chi)
+        return [o.to_tensor(as_torch=True) for o in objs]
 
     def single_step():
         o = NDMPS.from_tensor(x, mode=args.mode, max_bond=args.chi)
@@ -118,9 +131,24 @@ def main():
     value = world * args.batch * n_vox * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
 
-    # single-volume latency (batch of one), same kernels; not part of `value`
-    single_ms = float("nan")
+    # reference points, same kernels, not part of `value`: one lockstep group of 8 on one stream
+    # (with per-stage device times undisturbed by concurrent groups) and a single volume
+    single_ms = group8_ms = float("nan")
+    stages_group8 = {}
     if not args.skip_single:
+        n8 = min(8, args.batch)
+        group_step(n8)
+        timer8 = ndmps_mod.StageTimer()
+        ndmps_mod.set_stage_timer(timer8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            group_step(n8)
+        torch.cuda.synchronize()
+        group8_ms = (time.perf_counter() - t0) / 3 * 1e3
+        ndmps_mod.set_stage_timer(None)
+        stages_group8 = {k: {"ms_per_step": v[0] / 3, "launches_per_step": v[1] / 3}
+                         for k, v in timer8.totals_ms().items()}
         single_step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -129,24 +157,33 @@ def main():
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t0) / 3 * 1e3
 
-    # roofline of the reshape stage (the HBM-bound kernel north_star names): the tiled
-    # encode_permute kernel reads 4 B and writes 4 B per voxel, one launch per step.
-    perm = stages.get("encode_permute", {})
-    perm_ms = perm.get("ms_per_step", float("nan")) / max(perm.get("launches_per_step", 1.0), 1.0)
+    # roofline of the reshape stage (the HBM-bound kernel north_star names): the tiled encode_permute
+    # kernel reads 4 B and writes 4 B per voxel, one launch per volume.  Its launch duration is taken
+    # from the HIP events of the one-group phase of THIS run (nothing else on the GPU); the events of
+    # the concurrent main region also count the time a launch shares HBM with, or queues behind, the
+    # other groups' kernels and are reported next to it.
+    def per_launch_ms(st):
+        e = st.get("encode_permute", {})
+        return e.get("ms_per_step", float("nan")) / max(e.get("launches_per_step", 1.0), 1.0)
+
+    perm_ms_concurrent = per_launch_ms(stages)
+    perm_ms = per_launch_ms(stages_group8) if stages_group8 else perm_ms_concurrent
     algo_bytes = 2 * 4 * n_vox
     achieved = algo_bytes / (perm_ms * 1e-3) / 1e9
     roofline = {
-        "kernel": "encode_tiled_kernel<uint32>",
+        "kernel": "encode_tiled_kernel<uint32, vec>",
         "bound": "hbm",
         "achieved": achieved,
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE 66 019 KB + WRITE_SIZE 65 536 KB,
-        # profiles/r01_c_pmc_*.txt; this kernel's 4-B/lane sorted gather is tallied exactly, checked
-        # against its known 64 MiB read); only valid for the default 256^3 volume
+        # profiles/r01_c_pmc_*.txt; this kernel's sorted gather is tallied exactly, checked against its
+        # known 64 MiB read); only valid for the default 256^3 volume
         "traffic": (66019 + 65536) * 1024.0 if args.size == 256 else None,
         "read_frac": (4 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
+        "launch_us": perm_ms * 1e3,
+        "launch_us_in_concurrent_region": perm_ms_concurrent * 1e3,
         "end_to_end_algorithmic_GBps": args.batch * algo_bytes / (ms_per_step * 1e-3) / 1e9,
     }
 
@@ -164,17 +201,21 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"batch of {args.batch} independent {args.size}^3 fp32 synthetic MRI volumes per GPU per step, "
+            "workload": f"batch of {args.batch} independent {args.size}^3 fp32 synthetic MRI volumes per GPU per step "
+                        f"({args.groups} concurrent groups, lockstep inside a group), "
                         f"NDMPS.from_tensors(max_bond={args.chi}, mode={args.mode}) + to_tensor each, "
                         f"device-resident in/out",
             "volumes_per_step": world * args.batch,
             "batch_per_gpu": args.batch,
+            "groups_per_gpu": args.groups,
             "bonds": obj.bond_sizes(),
             "parallelism": f"{world} independent volume shard(s), no data-path collective",
         },
         "roofline": roofline,
         "stages": stages,
         "single_volume": {"ms": single_ms, "Mvoxels_per_s": n_vox / single_ms / 1e3},
+        "one_group_of_8": {"ms": group8_ms, "Mvoxels_per_s": min(8, args.batch) * n_vox / group8_ms / 1e3,
+                           "stages": stages_group8},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -213,6 +254,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line))
+    pool.shutdown()
     if world > 1:
         dist.destroy_process_group()
 
