@@ -27,6 +27,7 @@
 // eigenproblems cost the sequential depth of one.  Before the first sweep each matrix is permuted
 // so that its diagonal is descending.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -37,11 +38,19 @@ namespace {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BS = 16;       // block size
-constexpr int PS = 2 * BS;   // pair size (LDS sub-problem edge)
-constexpr int LD = PS + 1;   // padded LDS row
+// Block size BS (template parameter of the step kernel): 16 = 256 threads and four 32x32 LDS tiles
+// (33 KB, 4 workgroups per CU).  BS = 32 (1024 threads, four 64x64 tiles = 133 KB) halves the outer
+// steps per sweep and with them the trips of G and V through the cache hierarchy, but measured
+// SLOWER on MI355X (256^3, chi 64: single volume 36 vs 26 ms, group of 8: 55 vs 45 ms): the diag role's
+// inner step moves 4x the LDS bytes per barrier (1.15 vs 0.55 us) and one workgroup per CU starves the
+// apply role.  It stays selectable with NDMPS_EIG_BLOCK=32 (n >= 256) for experiments and is
+// covered by a test.
 constexpr int kMaxSweepsBlock = 40;
-constexpr int kTilesPerWg = 8;  // column pairs streamed by one apply workgroup
+inline int block_size_for(int64_t n_max) {
+  const char* e = getenv("NDMPS_EIG_BLOCK");
+  return (e && atoi(e) == 32 && n_max >= 256) ? 32 : 16;
+}
+inline int tiles_per_wg(int bs) { return bs == 32 ? 4 : 8; }  // column pairs streamed by one apply workgroup
 
 // one entry per matrix of the batch (device array); blockIdx.y selects it in every kernel
 struct BatchDesc {
@@ -67,6 +76,7 @@ struct Work {          // common padded working set; per-matrix strides np*np an
   double* sign;        // [B][np]
   int np;
   int nb;
+  int bs;              // block size the matrices are cut into (16 or 32)
 };
 
 // circle-method pairing of `count` players (even), round `step`: pair k -> (a, b)
@@ -226,15 +236,16 @@ __global__ void blk_check_kernel(BatchDesc* __restrict__ desc, int batch, int sw
 }
 
 // ---------------------------------------------------------------------------- step kernel
-// C(32x32) = op(A) * B in LDS, f64 MFMA; 4 waves, one 16x16 output tile each.
+// C(PS x PS) = op(A) * B in LDS, f64 MFMA; (PS/16)^2 waves, one 16x16 output tile each.
 // TRANS_A: A given as (k, i) (i.e. C = A^T B).
-template <bool TRANS_A>
-__device__ __forceinline__ void lds_gemm32(const double (*A)[LD], const double (*B)[LD], double (*Cout)[LD],
-                                           int wave, int lane) {
-  const int i0 = (wave >> 1) * 16, j0 = (wave & 1) * 16;
+template <int BS, bool TRANS_A>
+__device__ __forceinline__ void lds_gemm(const double (*A)[2 * BS + 1], const double (*B)[2 * BS + 1],
+                                         double (*Cout)[2 * BS + 1], int wave, int lane) {
+  constexpr int PS = 2 * BS, TPR = PS / 16;
+  const int i0 = (wave / TPR) * 16, j0 = (wave % TPR) * 16;
   const int li = lane & 15, lk = lane >> 4;
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
+#pragma unroll 8
   for (int k0 = 0; k0 < PS; k0 += 4) {
     const double a = TRANS_A ? A[k0 + lk][i0 + li] : A[i0 + li][k0 + lk];
     const double b = B[k0 + lk][j0 + li];
@@ -275,7 +286,8 @@ __device__ __forceinline__ void locate_block(int x, int t, int nb, int& k, int& 
   pos = x < partner ? 0 : 1;
 }
 
-__device__ __forceinline__ int64_t pair_index(int e, int lo, int hi) {  // e in [0, 32)
+template <int BS>
+__device__ __forceinline__ int64_t pair_index(int e, int lo, int hi) {  // e in [0, 2 BS)
   return e < BS ? (int64_t)lo * BS + e : (int64_t)hi * BS + e - BS;
 }
 
@@ -286,23 +298,26 @@ __device__ __forceinline__ int64_t pair_index(int e, int lo, int hi) {  // e in 
 //   first    : diag role reads the initial matrix directly (nothing to apply yet)
 //   solve    : single block pair = whole matrix, iterate to convergence in LDS
 //   in, out  : G ping-pong indices;  q_cur: parity of the Q / D buffers being applied
-__global__ void __launch_bounds__(256)
+template <int BS>
+__global__ void __launch_bounds__(BS * BS)
 blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_next, int full_next,
-                int sweep_next, int first, int solve, int in, int q_cur) {
+                int sweep_next, int first, int solve, int in, int q_cur, int kTilesPerWg) {
+  constexpr int PS = 2 * BS, LD = PS + 1, NT = BS * BS;  // pair size, padded LDS row, threads
   BatchDesc& d = desc[blockIdx.y];
   if (d.done) return;
-  // four 32x32 tiles of LDS, shared by both roles (33 KB -> 4 workgroups per CU):
+  // four PS x PS tiles of (dynamic) LDS, shared by both roles (33 KB at BS = 16, 133 KB at BS = 32):
   //   apply: T, QA, QB, X.   diag: the same four while the sub-matrix is built, then
   //   Q = QA's slot, S ping-pong = X's and QB's slots (all dead by then), T unused.
-  __shared__ double tiles[4][PS][LD];
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   __shared__ int cnt;
-  double (*T)[LD] = tiles[0];
-  double (*QA)[LD] = tiles[1];
-  double (*QB)[LD] = tiles[2];
-  double (*X)[LD] = tiles[3];
-  double (*Q)[LD] = tiles[1];
-  double (*S0)[LD] = tiles[3];
-  double (*S1)[LD] = tiles[2];
+  typedef double (*tile_t)[LD];
+  tile_t T = reinterpret_cast<tile_t>(lds_raw);
+  tile_t QA = reinterpret_cast<tile_t>(lds_raw + PS * LD);
+  tile_t QB = reinterpret_cast<tile_t>(lds_raw + 2 * PS * LD);
+  tile_t X = reinterpret_cast<tile_t>(lds_raw + 3 * PS * LD);
+  tile_t Q = QA;
+  tile_t S0 = X;
+  tile_t S1 = QB;
 
   const int np = w.np, nb = w.nb, half = nb >> 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -332,8 +347,8 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     }
     int lo_a = 0, hi_a = 0;
     if (is_g) pair_blocks(pa, t, nb, lo_a, hi_a);
-    const int row = tid >> 3, c0 = (tid & 7) * 2;  // this thread's row and column offset inside a 16-block
-    const int64_t grow = is_g ? pair_index(row, lo_a, hi_a) : (int64_t)strip * PS + row;
+    const int row = tid / (BS / 2), c0 = (tid % (BS / 2)) * 2;  // this thread's row and column offset inside a block
+    const int64_t grow = is_g ? pair_index<BS>(row, lo_a, hi_a) : (int64_t)strip * PS + row;
     const double* Min = is_g ? Gin : V;
     double* Mout = is_g ? Gout : V;
     if (is_g) {
@@ -382,11 +397,11 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       QB[row][BS + c0 + 1] = q1.y;
       if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);  // in flight during the two GEMMs
       __syncthreads();
-      lds_gemm32<false>(T, QB, X, wave, lane);  // X = T Q_B
+      lds_gemm<BS, false>(T, QB, X, wave, lane);  // X = T Q_B
       __syncthreads();
       double (*res)[LD] = X;
       if (is_g) {
-        lds_gemm32<true>(QA, X, T, wave, lane);  // T = Q_A^T X
+        lds_gemm<BS, true>(QA, X, T, wave, lane);  // T = Q_A^T X
         __syncthreads();
         res = T;
       }
@@ -407,9 +422,9 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
   const double tol_rot = d.tol_rot, tol_conv = d.tol_conv;
   if (tid == 0) cnt = 0;
   if (first) {
-    for (int e = tid; e < PS * PS; e += 256) {
+    for (int e = tid; e < PS * PS; e += NT) {
       const int a = e / PS, b = e % PS;
-      const int64_t ga = pair_index(a, lo, hi), gb = pair_index(b, lo, hi);
+      const int64_t ga = pair_index<BS>(a, lo, hi), gb = pair_index<BS>(b, lo, hi);
       S0[a][b] = 0.5 * (Gin[ga * np + gb] + Gin[gb * np + ga]);
       Q[a][b] = (a == b) ? 1.0 : 0.0;
     }
@@ -422,21 +437,21 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     int a_lo, a_hi, b_lo, b_hi;
     pair_blocks(ka, t, nb, a_lo, a_hi);
     pair_blocks(kb, t, nb, b_lo, b_hi);
-    const int r16 = tid >> 4, c16 = tid & 15;  // one element of every 16 x 16 block per thread
+    const int r16 = tid / BS, c16 = tid % BS;  // one element of every BS x BS block per thread
     // diagonal 16x16 blocks from the prepared diagonal tiles of step t (kept in registers
     // until the LDS slots they go to are free)
     const double d_lo = Dcur[(int64_t)ka * PS * PS + (pa * BS + r16) * PS + pa * BS + c16];
     const double d_hi = Dcur[(int64_t)kb * PS * PS + (pb * BS + r16) * PS + pb * BS + c16];
-    for (int e = tid; e < PS * PS; e += 256) {
+    for (int e = tid; e < PS * PS; e += NT) {
       const int a = e / PS, b = e % PS;
-      T[a][b] = Gin[pair_index(a, a_lo, a_hi) * np + pair_index(b, b_lo, b_hi)];
+      T[a][b] = Gin[pair_index<BS>(a, a_lo, a_hi) * np + pair_index<BS>(b, b_lo, b_hi)];
       QA[a][b] = Qcur[(int64_t)ka * PS * PS + e];
       QB[a][b] = Qcur[(int64_t)kb * PS * PS + e];
     }
     __syncthreads();
-    lds_gemm32<false>(T, QB, X, wave, lane);  // X = T Q_B
+    lds_gemm<BS, false>(T, QB, X, wave, lane);  // X = T Q_B
     __syncthreads();
-    lds_gemm32<true>(QA, X, T, wave, lane);  // T = Q_A^T X  (tile (ka, kb) after step t)
+    lds_gemm<BS, true>(QA, X, T, wave, lane);  // T = Q_A^T X  (tile (ka, kb) after step t)
     __syncthreads();
     {
       const double v = T[pa * BS + r16][pb * BS + c16];  // cross block (lo, hi)
@@ -445,11 +460,11 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       S0[r16][c16] = d_lo;
       S0[BS + r16][BS + c16] = d_hi;
     }
-    for (int e = tid; e < PS * PS; e += 256) Q[e / PS][e % PS] = (e / PS == e % PS) ? 1.0 : 0.0;
+    for (int e = tid; e < PS * PS; e += NT) Q[e / PS][e % PS] = (e / PS == e % PS) ? 1.0 : 0.0;
     __syncthreads();
   }
 
-  const int K = tid >> 4, M = tid & 15;
+  const int K = tid / BS, M = tid % BS;
   const int n_inner = full_next ? PS - 1 : BS;
   const int max_rounds = solve ? kMaxSweepsBlock : 1;
   const int r0 = 2 * K, r1 = 2 * K + 1;  // this thread's (static) rows of Q
@@ -474,8 +489,8 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       __syncthreads();  // nobody may bump cnt for this round before everyone has read it
     }
     for (int st = 0; st < n_inner; ++st) {
-      double (*S)[LD] = cur ? S1 : S0;
-      double (*Sn)[LD] = cur ? S0 : S1;
+      tile_t S = cur ? S1 : S0;
+      tile_t Sn = cur ? S0 : S1;
       int p, q, r, s_;
       if (full_next) {
         circle_pair(K, st, PS, p, q);
@@ -525,7 +540,7 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
   if (pending) flush_q();
   __syncthreads();
 
-  for (int e = tid; e < PS * PS; e += 256) {
+  for (int e = tid; e < PS * PS; e += NT) {
     Dnext[(int64_t)blockIdx.x * PS * PS + e] = (cur ? S1 : S0)[e / PS][e % PS];
     Qnext[(int64_t)blockIdx.x * PS * PS + e] = Q[e / PS][e % PS];
   }
@@ -612,6 +627,7 @@ struct BlockLayout {
 
 BlockLayout block_layout(int64_t n_max, int64_t batch) {
   BlockLayout l;
+  const int BS = block_size_for(n_max), PS = 2 * BS;
   l.np = std::max<int64_t>(ndmps::round_up(n_max, PS), PS);
   l.nb = l.np / BS;
   int64_t used = 0;
@@ -655,9 +671,28 @@ int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, v
   w.sign = (double*)(base + l.off_sign);
   w.np = (int)l.np;
   w.nb = (int)l.nb;
+  w.bs = block_size_for(n_max);
   BatchDesc* desc = (BatchDesc*)(base + l.off_desc);
   int* flag = (int*)(base + l.off_flag);
   const int np = w.np, nb = w.nb, half = nb / 2;
+  const int BS = w.bs, PS = 2 * BS, kTilesPerWg = tiles_per_wg(BS);
+  const size_t lds_bytes = (size_t)4 * PS * (PS + 1) * sizeof(double);
+  static bool attr_set = false;  // 133 KB of dynamic LDS needs an explicit opt-in (once per process)
+  if (!attr_set) {
+    NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_step_kernel<32>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 65 * 8));
+    attr_set = true;
+  }
+  // one launch of the step kernel (both block sizes share the argument list)
+  auto step = [&](unsigned gx, int n_diag, int t, int t_next, int full_next, int sweep_next, int first, int solve,
+                  int in, int q_cur) {
+    if (BS == 32)
+      hipLaunchKernelGGL(blk_step_kernel<32>, dim3(gx, (unsigned)batch), dim3(1024), lds_bytes, s, desc, w, n_diag, t,
+                         t_next, full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg);
+    else
+      hipLaunchKernelGGL(blk_step_kernel<16>, dim3(gx, (unsigned)batch), dim3(256), lds_bytes, s, desc, w, n_diag, t,
+                         t_next, full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg);
+  };
   NDMPS_CHECK_HIP(hipMemcpyAsync(desc, host_desc.data(), sizeof(BatchDesc) * batch, hipMemcpyHostToDevice, s));
 
   const unsigned B = (unsigned)batch;
@@ -674,8 +709,8 @@ int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, v
   const int steps = nb - 1;  // outer steps per sweep
   if (nb == 2) {
     // every matrix is one block pair: solved in LDS by the diag role, then applied once
-    hipLaunchKernelGGL(blk_step_kernel, dim3(half, B), dim3(256), 0, s, desc, w, half, 0, 0, 1, 0, 1, 1, 0, 1);
-    hipLaunchKernelGGL(blk_step_kernel, dim3(n_apply, B), dim3(256), 0, s, desc, w, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    step(half, half, 0, 0, 1, 0, 1, 1, 0, 1);
+    step(n_apply, 0, 0, 0, 0, 0, 0, 0, 0, 0);
     hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, 0, 1, flag);
     NDMPS_LAUNCH_CHECK();
     sweeps = 1;
@@ -683,14 +718,13 @@ int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, v
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   } else {
     // prepare step 0 of sweep 0 from the initial matrix (diag role only; writes Q[0], D[0])
-    hipLaunchKernelGGL(blk_step_kernel, dim3(half, B), dim3(256), 0, s, desc, w, half, 0, 0, 1, 0, 1, 0, 0, 1);
+    step(half, half, 0, 0, 1, 0, 1, 0, 0, 1);
     int g = 0;  // global step counter: G buffer in = g & 1, Q/D parity of the step applied = g & 1
     while (sweeps < kMaxSweepsBlock) {
       for (int t = 0; t < steps; ++t, ++g) {
         const int t_next = (t + 1) % steps;
         const int sweep_next = sweeps + (t == steps - 1 ? 1 : 0);
-        hipLaunchKernelGGL(blk_step_kernel, dim3(half + n_apply, B), dim3(256), 0, s, desc, w, half, t, t_next,
-                           t_next == 0 ? 1 : 0, sweep_next, 0, 0, g & 1, g & 1);
+        step(half + n_apply, half, t, t_next, t_next == 0 ? 1 : 0, sweep_next, 0, 0, g & 1, g & 1);
       }
       hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, sweeps, g & 1, flag);
       NDMPS_LAUNCH_CHECK();

@@ -195,6 +195,24 @@ def _syevj(lib, g, simple=False):
     return w.cpu().numpy(), v.cpu().numpy(), sweeps.value
 
 
+def test_block_size_32_variant_of_the_step_kernel():
+    """The 64x64-tile instantiation (NDMPS_EIG_BLOCK=32, measured slower, kept for experiments)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    n = 300
+    a = rng.standard_normal((2 * n, n)) * np.logspace(0, -4, n)[None, :]
+    g = a.T @ a
+    os.environ["NDMPS_EIG_BLOCK"] = "32"
+    try:
+        w, v, sweeps = _syevj(lib, g)
+    finally:
+        del os.environ["NDMPS_EIG_BLOCK"]
+    ref = np.linalg.eigvalsh(g)[::-1]
+    assert np.abs(w - ref).max() <= 1e-12 * ref[0]
+    assert np.abs(v.T @ v - np.eye(n)).max() <= 1e-12
+    assert np.abs(g @ v - v * w[None, :]).max() <= 1e-12 * ref[0]
+
+
 @pytest.mark.parametrize("n", [5, 32, 40, 96, 512])
 def test_block_and_simple_jacobi_agree(n):
     lib = _lib.load()
