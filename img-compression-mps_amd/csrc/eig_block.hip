@@ -361,10 +361,12 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     }
     // software pipeline: the operands of tile j+1 are fetched into registers while tile j is in LDS
     double2 t0, t1, q0, q1;
+    // G is symmetric: only tiles with pb > pa are computed, each result is written to (pa, pb) and,
+    // transposed, to (pb, pa) -- half the reads and MFMAs, and G stays exactly symmetric
     auto fetch = [&](int pb_) {
       int lo_b_, hi_b_;
       pair_blocks(pb_, t, nb, lo_b_, hi_b_);
-      if (is_g && pa == pb_) return;  // diagonal tile: nothing to multiply
+      if (is_g && pb_ <= pa) return;  // diagonal tile (copied) or lower triangle (mirrored)
       t0 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)lo_b_ * BS + c0);
       t1 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)hi_b_ * BS + c0);
       q0 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb_ * PS * PS + row * PS + c0);
@@ -383,6 +385,10 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
         const double* dsrc = Dcur + (int64_t)pa * PS * PS + row * PS;
         *reinterpret_cast<double2*>(o0) = *reinterpret_cast<const double2*>(dsrc + c0);
         *reinterpret_cast<double2*>(o1) = *reinterpret_cast<const double2*>(dsrc + BS + c0);
+        if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);
+        continue;
+      }
+      if (is_g && pb < pa) {  // written by the workgroup that owns (pb, pa)
         if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);
         continue;
       }
@@ -407,6 +413,13 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       }
       *reinterpret_cast<double2*>(o0) = make_double2(res[row][c0], res[row][c0 + 1]);
       *reinterpret_cast<double2*>(o1) = make_double2(res[row][BS + c0], res[row][BS + c0 + 1]);
+      if (is_g) {  // mirror: tile (pb, pa) = res^T (LDS column reads, odd row stride: conflict-free)
+        const int64_t trow = pair_index<BS>(row, lo_b, hi_b);
+        *reinterpret_cast<double2*>(Mout + trow * np + (int64_t)lo_a * BS + c0) =
+            make_double2(res[c0][row], res[c0 + 1][row]);
+        *reinterpret_cast<double2*>(Mout + trow * np + (int64_t)hi_a * BS + c0) =
+            make_double2(res[BS + c0][row], res[BS + c0 + 1][row]);
+      }
     }
     return;
   }
