@@ -61,7 +61,7 @@ struct BatchDesc {
   int done;            // converged: later launches skip this matrix
   int rotated[2];      // rotations above tol_conv, per sweep parity
   int final_buf;       // which G buffer holds the converged matrix
-  int pad;
+  int steps_applied;   // outer steps applied when it converged (history mode: rotations to replay)
   double tol_conv;
   double tol_rot;
   double rel_tol;      // convergence threshold relative to max |diag| (input)
@@ -72,8 +72,13 @@ struct Work {          // common padded working set; per-matrix strides np*np an
   double* V;
   double* Q[2];        // rotations of the step being applied / being prepared
   double* D[2];        // rotated diagonal tiles, same parity scheme
-  int* pos;            // [B][np]
+  int* pos;            // [B][np] position of every index after the initial diagonal sort
+  int* rank;           // [B][np] rank of the eigenvalue held by working column c
+  int* invrank;        // [B][np] working column of the j-th largest eigenvalue
   double* sign;        // [B][np]
+  double* hist;        // history mode: every step's rotation blocks, [B][max_steps][nb/2][PS*PS]
+  int64_t hist_stride; // doubles per matrix in `hist`
+  int hist_mode;       // 1: V is not updated per step; eigenvectors are replayed from `hist` afterwards
   int np;
   int nb;
   int bs;              // block size the matrices are cut into (16 or 32)
@@ -195,7 +200,7 @@ __global__ void __launch_bounds__(256) blk_init_kernel(const BatchDesc* __restri
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / np), c = (int)(e % np);
     Gp[e] = 0.0;
-    Vp[e] = (r == c && r >= n) ? 1.0 : 0.0;
+    if (!w.hist_mode) Vp[e] = (r == c && r >= n) ? 1.0 : 0.0;  // history mode keeps no V
   }
 }
 __global__ void __launch_bounds__(256) blk_scatter_kernel(const BatchDesc* __restrict__ desc, Work w) {
@@ -209,14 +214,14 @@ __global__ void __launch_bounds__(256) blk_scatter_kernel(const BatchDesc* __res
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / n), c = (int)(e % n);
     Gp[(int64_t)pos[r] * np + pos[c]] = 0.5 * (G[(int64_t)r * n + c] + G[(int64_t)c * n + r]);
-    if (r == c) Vp[(int64_t)r * np + pos[r]] = 1.0;
+    if (r == c && !w.hist_mode) Vp[(int64_t)r * np + pos[r]] = 1.0;
   }
 }
 
 // after the launches of sweep `sweep`: a matrix whose sweep rotated nothing above tol_conv is done;
 // its converged G sits in buffer `buf_now`
 __global__ void blk_check_kernel(BatchDesc* __restrict__ desc, int batch, int sweep, int buf_now,
-                                 int* __restrict__ remaining) {
+                                 int steps_now, int* __restrict__ remaining) {
   __shared__ int left;
   if (threadIdx.x == 0) left = 0;
   __syncthreads();
@@ -225,6 +230,7 @@ __global__ void blk_check_kernel(BatchDesc* __restrict__ desc, int batch, int sw
       if (desc[b].rotated[sweep & 1] == 0) {
         desc[b].done = 1;
         desc[b].final_buf = buf_now;
+        desc[b].steps_applied = steps_now;
       } else {
         atomicAdd(&left, 1);
       }
@@ -301,7 +307,7 @@ __device__ __forceinline__ int64_t pair_index(int e, int lo, int hi) {  // e in 
 template <int BS>
 __global__ void __launch_bounds__(BS * BS)
 blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_next, int full_next,
-                int sweep_next, int first, int solve, int in, int q_cur, int kTilesPerWg) {
+                int sweep_next, int first, int solve, int in, int q_cur, int kTilesPerWg, int gstep) {
   constexpr int PS = 2 * BS, LD = PS + 1, NT = BS * BS;  // pair size, padded LDS row, threads
   BatchDesc& d = desc[blockIdx.y];
   if (d.done) return;
@@ -324,7 +330,10 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
   const int64_t mat = (int64_t)blockIdx.y * np * np;
   const int64_t qoff = (int64_t)blockIdx.y * half * PS * PS;
   const double* Gin = w.G[in] + mat;
-  const double* Qcur = w.Q[q_cur] + qoff;
+  // rotations of the step being applied: ping-pong buffer, or slot `gstep` of the history
+  const int64_t slot = (int64_t)half * PS * PS;
+  const double* Qcur = w.hist_mode ? w.hist + (int64_t)blockIdx.y * w.hist_stride + (int64_t)max(gstep, 0) * slot
+                                   : w.Q[q_cur] + qoff;
   const double* Dcur = w.D[q_cur] + qoff;
 
   if ((int)blockIdx.x >= n_diag) {
@@ -428,7 +437,8 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
   // the diag workgroups are the serial chain of the launch: let their waves win issue arbitration
   // against co-resident apply waves
   __builtin_amdgcn_s_setprio(3);
-  double* Qnext = w.Q[q_cur ^ 1] + qoff;
+  double* Qnext = w.hist_mode ? w.hist + (int64_t)blockIdx.y * w.hist_stride + (int64_t)(gstep + 1) * slot
+                              : w.Q[q_cur ^ 1] + qoff;
   double* Dnext = w.D[q_cur ^ 1] + qoff;
   int lo, hi;
   pair_blocks(blockIdx.x, t_next, nb, lo, hi);
@@ -564,8 +574,9 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
 }
 
 // ---------------------------------------------------------------------------- finish
-// rank of every eigenvalue (descending, ties by index) and sign of its eigenvector (largest
-// component positive; ties -> lowest row): one workgroup per index, block reductions
+// rank of every eigenvalue (descending, ties by index) and, when V was accumulated in the loop, the
+// sign of its eigenvector (largest component positive; ties -> lowest row): one workgroup per
+// index, block reductions
 __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restrict__ desc, Work w) {
   __shared__ int red[4];
   __shared__ double best_v[4];
@@ -573,7 +584,6 @@ __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restri
   const BatchDesc& d = desc[blockIdx.y];
   const int n = d.n, np = w.np;
   const double* G = w.G[d.final_buf] + (int64_t)blockIdx.y * np * np;
-  const double* V = w.V + (int64_t)blockIdx.y * np * np;
   const int i = blockIdx.x;
   if (i >= n) return;
   const double wi = G[(int64_t)i * np + i];
@@ -583,6 +593,15 @@ __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restri
     rk += (wj > wi) || (wj == wi && j < i);
   }
   rk = block_sum_int(rk, red);
+  if (w.hist_mode) {
+    if (threadIdx.x == 0) {
+      w.rank[(int64_t)blockIdx.y * np + i] = rk;
+      w.invrank[(int64_t)blockIdx.y * np + rk] = i;
+      d.w_out[rk] = wi;
+    }
+    return;
+  }
+  const double* V = w.V + (int64_t)blockIdx.y * np * np;
   // arg max |V[r][i]| with the lowest r on ties (matches a sequential scan with '>')
   double bv = -1.0;
   int br = 0x7fffffff;
@@ -613,9 +632,91 @@ __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restri
         br = best_r[k];
       }
     const double v = br < n ? V[(int64_t)br * np + i] : 1.0;
-    w.pos[(int64_t)blockIdx.y * np + i] = rk;
+    w.rank[(int64_t)blockIdx.y * np + i] = rk;
     w.sign[(int64_t)blockIdx.y * np + i] = v < 0.0 ? -1.0 : 1.0;
     d.w_out[rk] = wi;
+  }
+}
+
+// History mode: eigenvectors by replaying the rotations.  V = P Q_0 Q_1 ... Q_{T-1} (P: initial sort,
+// Q_t: block-diagonal over step t's pairing), so column c of V is P Q_0 ... Q_{T-1} e_c.  One
+// workgroup keeps 16 columns (np x 16 doubles) in LDS and applies Q_{T-1} ... Q_0 to them: per step
+// each wave multiplies the 32-row slices of its block pairs by the stored 32x32 blocks (f64 MFMA).
+// Nothing but the rotation blocks is read from memory, and only the k wanted columns are formed --
+// the in-loop update streams all np x np of V through the cache hierarchy every step.
+// grid (ceil(k_max / 16), batch); dynamic LDS: np*17 + 4*32*33 doubles.
+__global__ void __launch_bounds__(256)
+blk_backacc_kernel(const BatchDesc* __restrict__ desc, Work w, const int* __restrict__ kcols) {
+  constexpr int BS = 16, PS = 32, LDJ = PS + 1, LDY = 17;
+  const BatchDesc& d = desc[blockIdx.y];
+  const int n = d.n, np = w.np, nb = w.nb, half = nb >> 1;
+  const int k = kcols[blockIdx.y];
+  const int col0 = blockIdx.x * 16;
+  if (col0 >= k) return;
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  double* Y = lds_raw;                                  // [np][LDY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double (*J)[LDJ] = reinterpret_cast<double (*)[LDJ]>(lds_raw + (int64_t)np * LDY + wave * PS * LDJ);
+  const int* invrank = w.invrank + (int64_t)blockIdx.y * np;
+  for (int e = tid; e < np * LDY; e += 256) Y[e] = 0.0;
+  __syncthreads();
+  if (tid < 16 && col0 + tid < k) Y[invrank[col0 + tid] * LDY + tid] = 1.0;
+  __syncthreads();
+
+  const double* hist = w.hist + (int64_t)blockIdx.y * w.hist_stride;
+  const int64_t slot = (int64_t)half * PS * PS;
+  const int li = lane & 15, lk = lane >> 4;
+  const int steps = d.steps_applied, per_sweep = nb - 1;
+  for (int st = steps - 1; st >= 0; --st) {
+    const int t = st % per_sweep;
+    for (int p = wave; p < half; p += 4) {
+      int lo, hi;
+      pair_blocks(p, t, nb, lo, hi);
+      const double* src = hist + (int64_t)st * slot + (int64_t)p * PS * PS;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // 1024 doubles, 2 per lane and pass
+        const int e = 2 * lane + 128 * i;
+        const double2 v = *reinterpret_cast<const double2*>(src + e);
+        J[e / PS][e % PS] = v.x;
+        J[e / PS][e % PS + 1] = v.y;
+      }
+      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k0 = 0; k0 < PS; k0 += 4) {
+        const int kr = k0 + lk;  // row of the pair slice this lane feeds as B[k][j]
+        const double yb = Y[(kr < BS ? lo * BS + kr : hi * BS + kr - BS) * LDY + li];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(J[li][kr], yb, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(J[16 + li][kr], yb, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // rows 0..15 of the slice live in block lo, 16..31 in block hi
+        Y[(lo * BS + lk + 4 * r) * LDY + li] = acc0[r];
+        Y[(hi * BS + lk + 4 * r) * LDY + li] = acc1[r];
+      }
+    }
+    __syncthreads();  // the next step regroups the rows
+  }
+
+  // sign convention (largest component positive, lowest row on ties) and the initial permutation
+  __shared__ double sgn[16];
+  if (tid < 16) {
+    double best = -1.0, val = 1.0;
+    const int* pos = w.pos + (int64_t)blockIdx.y * np;
+    for (int r = 0; r < n; ++r) {  // original row order, as the in-loop path scans V
+      const double v = Y[pos[r] * LDY + tid];
+      if (fabs(v) > best) {
+        best = fabs(v);
+        val = v;
+      }
+    }
+    sgn[tid] = val < 0.0 ? -1.0 : 1.0;
+  }
+  __syncthreads();
+  const int* pos = w.pos + (int64_t)blockIdx.y * np;
+  double* Vout = d.V_out;
+  for (int e = tid; e < n * 16; e += 256) {
+    const int r = e >> 4, j = e & 15;
+    if (col0 + j < k) Vout[(int64_t)r * n + col0 + j] = sgn[j] * Y[pos[r] * LDY + j];
   }
 }
 
@@ -623,7 +724,7 @@ __global__ void __launch_bounds__(256) blk_gather_kernel(const BatchDesc* __rest
   const BatchDesc& d = desc[blockIdx.y];
   const int n = d.n, np = w.np;
   const double* V = w.V + (int64_t)blockIdx.y * np * np;
-  const int* rank = w.pos + (int64_t)blockIdx.y * np;
+  const int* rank = w.rank + (int64_t)blockIdx.y * np;
   const double* sign = w.sign + (int64_t)blockIdx.y * np;
   double* Vout = d.V_out;
   const int64_t total = (int64_t)n * n;
@@ -633,9 +734,23 @@ __global__ void __launch_bounds__(256) blk_gather_kernel(const BatchDesc* __rest
   }
 }
 
+// History mode is used for batches (the throughput path) of matrices that fit the LDS-resident
+// replay (np <= 896 at 16 columns per workgroup) with the 16-wide blocking.
+constexpr int kHistMaxNp = 896;  // np * 17 + 4 * 32 * 33 doubles must fit the 160 KB of LDS
+inline bool use_history(int64_t n_max, int batch) {
+  const char* e = getenv("NDMPS_EIG_HISTORY");  // 0 / 1 force it off / on (experiments, tests)
+  const int64_t np = std::max<int64_t>(ndmps::round_up(n_max, 32), 32);
+  if (block_size_for(n_max) != 16 || np > kHistMaxNp) return false;
+  if (e) return atoi(e) != 0;
+  return batch >= 2;
+}
+
 struct BlockLayout {
   int64_t np, nb;
-  int64_t off_g[2], off_v, off_q[2], off_d[2], off_desc, off_pos, off_sign, off_flag, total;
+  int hist;
+  int64_t hist_stride;  // doubles per matrix
+  int64_t off_g[2], off_v, off_q[2], off_d[2], off_desc, off_pos, off_rank, off_invrank, off_sign, off_flag,
+      off_k, off_hist, total;
 };
 
 BlockLayout block_layout(int64_t n_max, int64_t batch) {
@@ -643,6 +758,7 @@ BlockLayout block_layout(int64_t n_max, int64_t batch) {
   const int BS = block_size_for(n_max), PS = 2 * BS;
   l.np = std::max<int64_t>(ndmps::round_up(n_max, PS), PS);
   l.nb = l.np / BS;
+  l.hist = use_history(n_max, (int)batch) ? 1 : 0;
   int64_t used = 0;
   auto take = [&](int64_t bytes) {
     const int64_t off = ndmps::round_up(used, 256);
@@ -652,112 +768,190 @@ BlockLayout block_layout(int64_t n_max, int64_t batch) {
   const int64_t qbytes = batch * (l.nb / 2) * PS * PS * 8;
   l.off_g[0] = take(batch * l.np * l.np * 8);
   l.off_g[1] = take(batch * l.np * l.np * 8);
-  l.off_v = take(batch * l.np * l.np * 8);
-  l.off_q[0] = take(qbytes);
-  l.off_q[1] = take(qbytes);
+  l.off_v = take(l.hist ? 256 : batch * l.np * l.np * 8);
+  l.off_q[0] = take(l.hist ? 256 : qbytes);
+  l.off_q[1] = take(l.hist ? 256 : qbytes);
   l.off_d[0] = take(qbytes);
   l.off_d[1] = take(qbytes);
   l.off_desc = take(batch * (int64_t)sizeof(BatchDesc));
   l.off_pos = take(batch * l.np * 4);
+  l.off_rank = take(batch * l.np * 4);
+  l.off_invrank = take(batch * l.np * 4);
   l.off_sign = take(batch * l.np * 8);
   l.off_flag = take(256);
+  l.off_k = take(batch * 4);
+  // one slot of rotation blocks per outer step of up to kMaxSweepsBlock sweeps, plus the prepared one
+  l.hist_stride = l.hist ? ((int64_t)kMaxSweepsBlock * (l.nb - 1) + 1) * (l.nb / 2) * PS * PS : 0;
+  l.off_hist = take(l.hist ? batch * l.hist_stride * 8 : 256);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
 
-int solve_batched(int batch, std::vector<BatchDesc>& host_desc, int64_t n_max, void* d_ws, int64_t ws_bytes,
-                  int* h_sweeps, hipStream_t s) {
-  const BlockLayout l = block_layout(n_max, batch);
-  if (d_ws == nullptr || ws_bytes < l.total) {
-    ndmps::set_error("syevj workspace too small: %lld < %lld", (long long)ws_bytes, (long long)l.total);
-    return NDMPS_EWORKSPACE;
-  }
-  char* base = (char*)d_ws;
+// Solver state between the two phases: values() iterates to convergence and delivers the sorted
+// eigenvalues; vectors(k) delivers the first k eigenvectors of every matrix.
+struct BatchedJacobi {
+  int batch = 0;
+  int64_t n_max = 0;
+  BlockLayout l;
   Work w;
-  for (int i = 0; i < 2; ++i) {
-    w.G[i] = (double*)(base + l.off_g[i]);
-    w.Q[i] = (double*)(base + l.off_q[i]);
-    w.D[i] = (double*)(base + l.off_d[i]);
-  }
-  w.V = (double*)(base + l.off_v);
-  w.pos = (int*)(base + l.off_pos);
-  w.sign = (double*)(base + l.off_sign);
-  w.np = (int)l.np;
-  w.nb = (int)l.nb;
-  w.bs = block_size_for(n_max);
-  BatchDesc* desc = (BatchDesc*)(base + l.off_desc);
-  int* flag = (int*)(base + l.off_flag);
-  const int np = w.np, nb = w.nb, half = nb / 2;
-  const int BS = w.bs, PS = 2 * BS, kTilesPerWg = tiles_per_wg(BS);
-  const size_t lds_bytes = (size_t)4 * PS * (PS + 1) * sizeof(double);
-  static bool attr_set = false;  // 133 KB of dynamic LDS needs an explicit opt-in (once per process)
-  if (!attr_set) {
-    NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_step_kernel<32>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 65 * 8));
-    attr_set = true;
-  }
-  // one launch of the step kernel (both block sizes share the argument list)
-  auto step = [&](unsigned gx, int n_diag, int t, int t_next, int full_next, int sweep_next, int first, int solve,
-                  int in, int q_cur) {
-    if (BS == 32)
-      hipLaunchKernelGGL(blk_step_kernel<32>, dim3(gx, (unsigned)batch), dim3(1024), lds_bytes, s, desc, w, n_diag, t,
-                         t_next, full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg);
-    else
-      hipLaunchKernelGGL(blk_step_kernel<16>, dim3(gx, (unsigned)batch), dim3(256), lds_bytes, s, desc, w, n_diag, t,
-                         t_next, full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg);
-  };
-  NDMPS_CHECK_HIP(hipMemcpyAsync(desc, host_desc.data(), sizeof(BatchDesc) * batch, hipMemcpyHostToDevice, s));
+  BatchDesc* desc = nullptr;
+  int* flag = nullptr;
+  int* d_k = nullptr;
+  hipStream_t s = nullptr;
+  int sweeps = 0;
 
-  const unsigned B = (unsigned)batch;
-  const int fill_grid = (int)std::min<int64_t>(ndmps::ceil_div((int64_t)np * np, 256), 1024);
-  hipLaunchKernelGGL(blk_scale_kernel, dim3(1, B), dim3(256), 0, s, desc);
-  hipLaunchKernelGGL(blk_order_kernel, dim3((unsigned)n_max, B), dim3(256), 0, s, desc, w);
-  hipLaunchKernelGGL(blk_init_kernel, dim3(fill_grid, B), dim3(256), 0, s, desc, w);
-  hipLaunchKernelGGL(blk_scatter_kernel, dim3(fill_grid, B), dim3(256), 0, s, desc, w);
-  NDMPS_LAUNCH_CHECK();
+  int init(int batch_, std::vector<BatchDesc>& host_desc, int64_t n_max_, void* d_ws, int64_t ws_bytes,
+           hipStream_t stream) {
+    batch = batch_;
+    n_max = n_max_;
+    s = stream;
+    l = block_layout(n_max, batch);
+    if (d_ws == nullptr || ws_bytes < l.total) {
+      ndmps::set_error("syevj workspace too small: %lld < %lld", (long long)ws_bytes, (long long)l.total);
+      return NDMPS_EWORKSPACE;
+    }
+    char* base = (char*)d_ws;
+    for (int i = 0; i < 2; ++i) {
+      w.G[i] = (double*)(base + l.off_g[i]);
+      w.Q[i] = (double*)(base + l.off_q[i]);
+      w.D[i] = (double*)(base + l.off_d[i]);
+    }
+    w.V = (double*)(base + l.off_v);
+    w.pos = (int*)(base + l.off_pos);
+    w.rank = (int*)(base + l.off_rank);
+    w.invrank = (int*)(base + l.off_invrank);
+    w.sign = (double*)(base + l.off_sign);
+    w.hist = (double*)(base + l.off_hist);
+    w.hist_stride = l.hist_stride;
+    w.hist_mode = l.hist;
+    w.np = (int)l.np;
+    w.nb = (int)l.nb;
+    w.bs = block_size_for(n_max);
+    desc = (BatchDesc*)(base + l.off_desc);
+    flag = (int*)(base + l.off_flag);
+    d_k = (int*)(base + l.off_k);
+    NDMPS_CHECK_HIP(hipMemcpyAsync(desc, host_desc.data(), sizeof(BatchDesc) * batch, hipMemcpyHostToDevice, s));
+    return NDMPS_OK;
+  }
 
-  int sweeps = 0, remaining = 1;
-  const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
-  const int n_apply = half * chunks + (np / PS) * chunks;
-  const int steps = nb - 1;  // outer steps per sweep
-  if (nb == 2) {
-    // every matrix is one block pair: solved in LDS by the diag role, then applied once
-    step(half, half, 0, 0, 1, 0, 1, 1, 0, 1);
-    step(n_apply, 0, 0, 0, 0, 0, 0, 0, 0, 0);
-    hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, 0, 1, flag);
+  int values() {
+    const int np = w.np, nb = w.nb, half = nb / 2;
+    const int BS = w.bs, PS = 2 * BS, kTilesPerWg = tiles_per_wg(BS);
+    const size_t lds_bytes = (size_t)4 * PS * (PS + 1) * sizeof(double);
+    static bool attr_set = false;  // 133 KB of dynamic LDS needs an explicit opt-in (once per process)
+    if (!attr_set) {
+      NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_step_kernel<32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 65 * 8));
+      NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (kHistMaxNp * 17 + 4 * 32 * 33) * 8));
+      attr_set = true;
+    }
+    const unsigned B = (unsigned)batch;
+    // one launch of the step kernel (both block sizes share the argument list)
+    auto step = [&](unsigned gx, int n_diag, int t, int t_next, int full_next, int sweep_next, int first, int solve,
+                    int in, int q_cur, int gstep) {
+      if (BS == 32)
+        hipLaunchKernelGGL(blk_step_kernel<32>, dim3(gx, B), dim3(1024), lds_bytes, s, desc, w, n_diag, t, t_next,
+                           full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg, gstep);
+      else
+        hipLaunchKernelGGL(blk_step_kernel<16>, dim3(gx, B), dim3(256), lds_bytes, s, desc, w, n_diag, t, t_next,
+                           full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg, gstep);
+    };
+    const int fill_grid = (int)std::min<int64_t>(ndmps::ceil_div((int64_t)np * np, 256), 1024);
+    hipLaunchKernelGGL(blk_scale_kernel, dim3(1, B), dim3(256), 0, s, desc);
+    hipLaunchKernelGGL(blk_order_kernel, dim3((unsigned)n_max, B), dim3(256), 0, s, desc, w);
+    hipLaunchKernelGGL(blk_init_kernel, dim3(fill_grid, B), dim3(256), 0, s, desc, w);
+    hipLaunchKernelGGL(blk_scatter_kernel, dim3(fill_grid, B), dim3(256), 0, s, desc, w);
     NDMPS_LAUNCH_CHECK();
-    sweeps = 1;
-    NDMPS_CHECK_HIP(hipMemcpyAsync(&remaining, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-  } else {
-    // prepare step 0 of sweep 0 from the initial matrix (diag role only; writes Q[0], D[0])
-    step(half, half, 0, 0, 1, 0, 1, 0, 0, 1);
-    int g = 0;  // global step counter: G buffer in = g & 1, Q/D parity of the step applied = g & 1
-    while (sweeps < kMaxSweepsBlock) {
-      for (int t = 0; t < steps; ++t, ++g) {
-        const int t_next = (t + 1) % steps;
-        const int sweep_next = sweeps + (t == steps - 1 ? 1 : 0);
-        step(half + n_apply, half, t, t_next, t_next == 0 ? 1 : 0, sweep_next, 0, 0, g & 1, g & 1);
-      }
-      hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, sweeps, g & 1, flag);
+
+    int remaining = 1;
+    sweeps = 0;
+    const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
+    // history mode: the apply role has no V tiles
+    const int n_apply = half * chunks + (w.hist_mode ? 0 : (np / PS) * chunks);
+    const int steps = nb - 1;  // outer steps per sweep
+    if (nb == 2) {
+      // every matrix is one block pair: solved in LDS by the diag role, then applied once
+      step(half, half, 0, 0, 1, 0, 1, 1, 0, 1, -1);
+      step(n_apply, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+      hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, 0, 1, 1, flag);
       NDMPS_LAUNCH_CHECK();
-      ++sweeps;
+      sweeps = 1;
       NDMPS_CHECK_HIP(hipMemcpyAsync(&remaining, flag, sizeof(int), hipMemcpyDeviceToHost, s));
       NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-      if (remaining == 0) break;
+    } else {
+      // prepare step 0 of sweep 0 from the initial matrix (diag role only; writes Q[0] / slot 0, D[0])
+      step(half, half, 0, 0, 1, 0, 1, 0, 0, 1, -1);
+      int g = 0;  // global step counter: G buffer in = g & 1, Q/D parity of the step applied = g & 1
+      while (sweeps < kMaxSweepsBlock) {
+        for (int t = 0; t < steps; ++t, ++g) {
+          const int t_next = (t + 1) % steps;
+          const int sweep_next = sweeps + (t == steps - 1 ? 1 : 0);
+          step(half + n_apply, half, t, t_next, t_next == 0 ? 1 : 0, sweep_next, 0, 0, g & 1, g & 1, g);
+        }
+        hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, sweeps, g & 1, g, flag);
+        NDMPS_LAUNCH_CHECK();
+        ++sweeps;
+        NDMPS_CHECK_HIP(hipMemcpyAsync(&remaining, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+        if (remaining == 0) break;
+      }
     }
+    if (remaining != 0) {
+      ndmps::set_error("block Jacobi did not converge in %d sweeps (n=%lld, %d of %d matrices left)",
+                       kMaxSweepsBlock, (long long)n_max, remaining, batch);
+      return NDMPS_ENOCONV;
+    }
+    hipLaunchKernelGGL(blk_rank_kernel, dim3((unsigned)n_max, B), dim3(256), 0, s, desc, w);
+    NDMPS_LAUNCH_CHECK();
+    return NDMPS_OK;
   }
-  if (h_sweeps) *h_sweeps = sweeps;
-  if (remaining != 0) {
-    ndmps::set_error("block Jacobi did not converge in %d sweeps (n=%lld, %d of %d matrices left)",
-                     kMaxSweepsBlock, (long long)n_max, remaining, batch);
-    return NDMPS_ENOCONV;
+
+  // first h_k[b] eigenvectors of matrix b (columns 0..k-1 of its V_out); asynchronous on the stream
+  int vectors(const int64_t* h_k) {
+    const unsigned B = (unsigned)batch;
+    if (!w.hist_mode) {  // V was accumulated in the loop: sort and sign all of it
+      const int gather_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * n_max, 256), 2048);
+      hipLaunchKernelGGL(blk_gather_kernel, dim3(gather_grid, B), dim3(256), 0, s, desc, w);
+      NDMPS_LAUNCH_CHECK();
+      return NDMPS_OK;
+    }
+    std::vector<int> k32(batch);
+    int k_max = 1;
+    for (int b = 0; b < batch; ++b) {
+      k32[b] = (int)h_k[b];
+      k_max = std::max(k_max, k32[b]);
+    }
+    NDMPS_CHECK_HIP(hipMemcpyAsync(d_k, k32.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
+    NDMPS_CHECK_HIP(hipStreamSynchronize(s));  // k32 lives on this stack frame
+    const size_t lds = ((size_t)w.np * 17 + 4 * 32 * 33) * sizeof(double);
+    hipLaunchKernelGGL(blk_backacc_kernel, dim3((unsigned)ndmps::ceil_div(k_max, 16), B), dim3(256), lds, s, desc, w,
+                       d_k);
+    NDMPS_LAUNCH_CHECK();
+    return NDMPS_OK;
   }
-  hipLaunchKernelGGL(blk_rank_kernel, dim3((unsigned)n_max, B), dim3(256), 0, s, desc, w);
-  const int gather_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * n_max, 256), 2048);
-  hipLaunchKernelGGL(blk_gather_kernel, dim3(gather_grid, B), dim3(256), 0, s, desc, w);
-  NDMPS_LAUNCH_CHECK();
-  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+};
+
+int make_desc(int batch, double* d_G, int64_t stride_G, const int64_t* h_n, double* d_V, int64_t stride_V,
+              double* d_w, int64_t stride_w, double rel_tol, std::vector<BatchDesc>& desc, int64_t& n_max) {
+  NDMPS_REQUIRE(batch >= 1 && batch <= 4096, "batch=%d outside [1, 4096]", batch);
+  NDMPS_REQUIRE(rel_tol >= 1e-16 && rel_tol <= 1e-6, "rel_tol=%g outside [1e-16, 1e-6]", rel_tol);
+  NDMPS_REQUIRE(d_G && d_V && d_w && h_n, "NULL eigen operand");
+  desc.resize(batch);
+  n_max = 0;
+  for (int b = 0; b < batch; ++b) {
+    NDMPS_REQUIRE(h_n[b] >= 1 && h_n[b] <= 32768, "eigen size n=%lld outside [1, 32768]", (long long)h_n[b]);
+    NDMPS_REQUIRE(stride_G >= h_n[b] * h_n[b] && stride_V >= h_n[b] * h_n[b] && stride_w >= h_n[b],
+                  "batch stride smaller than a matrix");
+    n_max = std::max(n_max, h_n[b]);
+    memset(&desc[b], 0, sizeof(BatchDesc));
+    desc[b].G_in = d_G + b * stride_G;
+    desc[b].V_out = d_V + b * stride_V;
+    desc[b].w_out = d_w + b * stride_w;
+    desc[b].n = (int)h_n[b];
+    desc[b].rel_tol = rel_tol;
+  }
   return NDMPS_OK;
 }
 
@@ -774,24 +968,75 @@ extern "C" int ndmps_syevj_batched_tol_f64(int batch, double* d_G, int64_t strid
                                            double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
                                            double rel_tol, void* d_ws, int64_t ws_bytes, int* h_sweeps,
                                            ndmps_stream_t stream) {
-  NDMPS_REQUIRE(batch >= 1 && batch <= 4096, "batch=%d outside [1, 4096]", batch);
-  NDMPS_REQUIRE(rel_tol >= 1e-16 && rel_tol <= 1e-6, "rel_tol=%g outside [1e-16, 1e-6]", rel_tol);
-  NDMPS_REQUIRE(d_G && d_V && d_w && h_n, "NULL eigen operand");
-  std::vector<BatchDesc> desc(batch);
+  std::vector<BatchDesc> desc;
   int64_t n_max = 0;
-  for (int b = 0; b < batch; ++b) {
-    NDMPS_REQUIRE(h_n[b] >= 1 && h_n[b] <= 32768, "eigen size n=%lld outside [1, 32768]", (long long)h_n[b]);
-    NDMPS_REQUIRE(stride_G >= h_n[b] * h_n[b] && stride_V >= h_n[b] * h_n[b] && stride_w >= h_n[b],
-                  "batch stride smaller than a matrix");
-    n_max = std::max(n_max, h_n[b]);
-    memset(&desc[b], 0, sizeof(BatchDesc));
-    desc[b].G_in = d_G + b * stride_G;
-    desc[b].V_out = d_V + b * stride_V;
-    desc[b].w_out = d_w + b * stride_w;
-    desc[b].n = (int)h_n[b];
-    desc[b].rel_tol = rel_tol;
+  NDMPS_TRY(make_desc(batch, d_G, stride_G, h_n, d_V, stride_V, d_w, stride_w, rel_tol, desc, n_max));
+  BatchedJacobi jac;
+  NDMPS_TRY(jac.init(batch, desc, n_max, d_ws, ws_bytes, (hipStream_t)stream));
+  NDMPS_TRY(jac.values());
+  if (h_sweeps) *h_sweeps = jac.sweeps;
+  NDMPS_TRY(jac.vectors(h_n));  // all eigenvectors
+  NDMPS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return NDMPS_OK;
+}
+
+// Two-phase form used by the sweep: eigenvalues first (the caller derives the kept rank of every
+// matrix from them), then only the first h_k[b] eigenvectors.  d_ws must stay untouched in between.
+extern "C" int ndmps_syevj_batched_values_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n,
+                                              double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
+                                              double rel_tol, void* d_ws, int64_t ws_bytes, int* h_sweeps,
+                                              ndmps_stream_t stream) {
+  std::vector<BatchDesc> desc;
+  int64_t n_max = 0;
+  NDMPS_TRY(make_desc(batch, d_G, stride_G, h_n, d_V, stride_V, d_w, stride_w, rel_tol, desc, n_max));
+  BatchedJacobi jac;
+  NDMPS_TRY(jac.init(batch, desc, n_max, d_ws, ws_bytes, (hipStream_t)stream));
+  NDMPS_TRY(jac.values());
+  if (h_sweeps) *h_sweeps = jac.sweeps;
+  NDMPS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_syevj_batched_vectors_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n,
+                                               double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
+                                               const int64_t* h_k, void* d_ws, int64_t ws_bytes,
+                                               ndmps_stream_t stream) {
+  NDMPS_REQUIRE(h_k, "NULL rank array");
+  std::vector<BatchDesc> desc;
+  int64_t n_max = 0;
+  NDMPS_TRY(make_desc(batch, d_G, stride_G, h_n, d_V, stride_V, d_w, stride_w, 1e-15, desc, n_max));
+  for (int b = 0; b < batch; ++b) NDMPS_REQUIRE(h_k[b] >= 1 && h_k[b] <= h_n[b], "k out of range");
+  BatchedJacobi jac;
+  // re-attach to the workspace of the values phase without touching the device-side descriptors
+  jac.batch = batch;
+  jac.n_max = n_max;
+  jac.s = (hipStream_t)stream;
+  jac.l = block_layout(n_max, batch);
+  if (d_ws == nullptr || ws_bytes < jac.l.total) {
+    ndmps::set_error("syevj workspace too small");
+    return NDMPS_EWORKSPACE;
   }
-  return solve_batched(batch, desc, n_max, d_ws, ws_bytes, h_sweeps, (hipStream_t)stream);
+  char* base = (char*)d_ws;
+  for (int i = 0; i < 2; ++i) {
+    jac.w.G[i] = (double*)(base + jac.l.off_g[i]);
+    jac.w.Q[i] = (double*)(base + jac.l.off_q[i]);
+    jac.w.D[i] = (double*)(base + jac.l.off_d[i]);
+  }
+  jac.w.V = (double*)(base + jac.l.off_v);
+  jac.w.pos = (int*)(base + jac.l.off_pos);
+  jac.w.rank = (int*)(base + jac.l.off_rank);
+  jac.w.invrank = (int*)(base + jac.l.off_invrank);
+  jac.w.sign = (double*)(base + jac.l.off_sign);
+  jac.w.hist = (double*)(base + jac.l.off_hist);
+  jac.w.hist_stride = jac.l.hist_stride;
+  jac.w.hist_mode = jac.l.hist;
+  jac.w.np = (int)jac.l.np;
+  jac.w.nb = (int)jac.l.nb;
+  jac.w.bs = block_size_for(n_max);
+  jac.desc = (BatchDesc*)(base + jac.l.off_desc);
+  jac.d_k = (int*)(base + jac.l.off_k);
+  NDMPS_TRY(jac.vectors(h_k));
+  return NDMPS_OK;
 }
 
 extern "C" int ndmps_syevj_batched_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n, double* d_V,

@@ -271,21 +271,28 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
     }
     // ---- one batched eigen-solve for the site
     int sweeps = 0;
-    NDMPS_TRY(ndmps_syevj_batched_tol_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(),
-                                          ev_ws, ev_ws_bytes, &sweeps, s));
+    NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(),
+                                             ev_ws, ev_ws_bytes, &sweeps, s));
     NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
                                    hipMemcpyDeviceToHost, s));
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-    // ---- rank decision, core and carried matrix per volume
+    // ---- rank decision per volume, then only the kept eigenvectors
     for (int b = 0; b < batch; ++b) {
-      const int64_t n = h_dims[i] * chi_r[b];
       const int64_t small = eig_n[b];
       std::vector<double> sv(host_w.begin() + (int64_t)b * lay.small_max,
                              host_w.begin() + (int64_t)b * lay.small_max + small);
       for (auto& x : sv) x = sqrt(std::max(x, 0.0));
-      const int64_t k = kept_rank(sv, cutoff, max_bond);
+      kept[b] = kept_rank(sv, cutoff, max_bond);
       if (h_spectra && h_spec_offsets)
         memcpy(h_spectra + (int64_t)b * spec_total + h_spec_offsets[i], sv.data(), small * sizeof(double));
+    }
+    NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(),
+                                              ev_ws, ev_ws_bytes, s));
+    // ---- core and carried matrix per volume
+    for (int b = 0; b < batch; ++b) {
+      const int64_t n = h_dims[i] * chi_r[b];
+      const int64_t small = eig_n[b];
+      const int64_t k = kept[b];
       float* core = h_cores[b] + h_core_offsets[i];
       double* Vb = V + (int64_t)b * sq;
       double* wb = w + (int64_t)b * lay.small_max;

@@ -135,6 +135,19 @@ int ndmps_syevj_batched_tol_f64(int batch, double* d_G, int64_t stride_G, const 
                                 double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
                                 double rel_tol, void* d_ws, int64_t ws_bytes, int* h_sweeps,
                                 ndmps_stream_t stream);
+/* two-phase form (used by the sweep): eigenvalues first -- the caller derives the kept rank of every
+ * matrix from them -- then only the first h_k[b] eigenvectors (columns 0..k-1 of V).  Same arguments
+ * in both calls; d_ws must stay untouched in between.  For batches of matrices up to 896 the solver
+ * does not update V per step: it records every step's rotation blocks in d_ws and replays them on the
+ * k wanted columns held in LDS. */
+int ndmps_syevj_batched_values_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n,
+                                   double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
+                                   double rel_tol, void* d_ws, int64_t ws_bytes, int* h_sweeps,
+                                   ndmps_stream_t stream);
+int ndmps_syevj_batched_vectors_f64(int batch, double* d_G, int64_t stride_G, const int64_t* h_n,
+                                    double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
+                                    const int64_t* h_k, void* d_ws, int64_t ws_bytes,
+                                    ndmps_stream_t stream);
 /* same contract, scalar-parallel Jacobi (one launch per rotation step); kept as the
  * cross-check of the block solver above */
 int64_t ndmps_syevj_simple_workspace_bytes(int64_t n);
