@@ -24,6 +24,8 @@ SIGNATURES = {
     "ndmps_version": (C.c_int, []),
     "ndmps_last_error": (C.c_char_p, []),
     "ndmps_device_count": (C.c_int, []),
+    "ndmps_streams_create": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(C.c_int)]),
+    "ndmps_streams_destroy": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "ndmps_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, p_i64, C.c_int, p_i64]),
     "ndmps_plan_destroy": (C.c_int, [vp]),
     "ndmps_plan_numel": (i64, [vp]),

@@ -42,6 +42,30 @@ def _split(n_items: int, groups: int):
     return [shard_indices(n_items, g, groups) for g in range(groups)]
 
 
+_group_streams = {}
+
+
+def group_streams(n: int):
+    """n long-lived HIP streams of the current device on different hardware queues
+    (``ndmps_streams_create`` measures the binding).  Long-lived for two reasons: torch's caching
+    allocator pools memory per stream (a fresh stream per call would hipMalloc ~6 GB of workspace per
+    group every time), and the queue binding is decided once, at a stream's first use."""
+    import ctypes as C
+
+    import torch
+
+    from .. import _lib
+
+    key = (torch.cuda.current_device(), n)
+    if key not in _group_streams:
+        lib = _lib.load()
+        raw = (C.c_void_p * n)()
+        found = C.c_int(0)
+        _lib.check(lib.ndmps_streams_create(n, raw, C.byref(found)))
+        _group_streams[key] = [torch.cuda.ExternalStream(int(raw[i])) for i in range(n)]
+    return _group_streams[key]
+
+
 def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str = "Std", norm: bool = False,
                              max_bond=None, cutoff: float = 1e-10, reconstruct: bool = True, pool=None):
     """Throughput path for a list of same-shape device volumes: the list is cut into ``groups``
@@ -61,8 +85,13 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
     ready = torch.cuda.Event()
     ready.record(main)
 
-    def work(idx):
-        stream = torch.cuda.Stream()
+    device_index = torch.cuda.current_device()
+    streams = group_streams(len(parts))
+
+    def work(slot):
+        idx = parts[slot]
+        torch.cuda.set_device(device_index)  # pool threads start on device 0
+        stream = streams[slot]
         with torch.cuda.stream(stream):
             stream.wait_event(ready)  # inputs produced on the caller's stream
             objs = NDMPS.from_tensors([tensor_list[i] for i in idx], norm=norm, mode=mode, max_bond=max_bond,
@@ -76,7 +105,7 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
     if own_pool:
         pool = ThreadPoolExecutor(len(parts))
     try:
-        results = list(pool.map(work, parts))
+        results = list(pool.map(work, range(len(parts))))
     finally:
         if own_pool:
             pool.shutdown()

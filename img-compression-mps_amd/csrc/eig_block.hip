@@ -344,13 +344,113 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     double* V = w.V + mat;
     const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
     int bid = blockIdx.x - n_diag;
-    const bool is_g = bid < half * chunks;
+    if constexpr (BS == 16) {
+      // G tiles, register-only: one WAVE = one 16-column half of one upper tile (pa < pb), no LDS
+      // and no barrier.  With R = Q_A^T T Q_B, the wave computes the half  R^T[:, h] = Q_B^T (T^T Q_A[:, h]):
+      // the accumulator of the first product (row 4r + lk, column li) IS the B operand of the second
+      // (k = 4s + lk), so nothing is transposed or staged; all operands are read from global / L2
+      // straight into MFMA layout (128-byte row segments).  half^2 wave items per matrix:
+      // `half` copies of the prepared diagonal tiles + 2 per upper tile.
+      const int g_wgs = (half * half + 3) >> 2;
+      if (bid < g_wgs) {
+        const int wid = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
+        if (wid >= half * half) return;
+        double* Gout = w.G[in ^ 1] + mat;
+        const int li = lane & 15, lk = lane >> 4;
+        if (wid < half) {  // diagonal tile: prepared (already rotated) by the diag role
+          int lo, hi;
+          pair_blocks(wid, t, nb, lo, hi);
+          const double* dsrc = Dcur + (int64_t)wid * PS * PS;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int e = 2 * lane + 128 * q;
+            *reinterpret_cast<double2*>(Gout + pair_index<BS>(e / PS, lo, hi) * np + pair_index<BS>(e % PS, lo, hi)) =
+                *reinterpret_cast<const double2*>(dsrc + e);
+          }
+          return;
+        }
+        const int u2 = wid - half, h = u2 & 1;
+        int u = u2 >> 1, pa = 0;
+        while (u >= half - 1 - pa) {
+          u -= half - 1 - pa;
+          ++pa;
+        }
+        const int pb = pa + 1 + u;
+        int lo_a, hi_a, lo_b, hi_b;
+        pair_blocks(pa, t, nb, lo_a, hi_a);
+        pair_blocks(pb, t, nb, lo_b, hi_b);
+        const double* qa = Qcur + (int64_t)pa * PS * PS + lk * PS + 16 * h + li;
+        const double* qb = Qcur + (int64_t)pb * PS * PS + lk * PS + li;
+        // G is symmetric and only its block-upper half is kept (16x16 block (x, y) with x < y; the
+        // diagonal blocks travel in the prepared diagonal tiles): a block with x > y is read, and
+        // written, through its mirror image -- 32-byte pieces instead of 128-byte rows, same bytes.
+        // That halves the write traffic of a step, which is what bounds the kernel once several
+        // matrices are in flight (measured ~4 TB/s of G traffic).
+        auto block_ptr = [&](int x, int y, int64_t& sx, int64_t& sy) -> int64_t {  // &G[x rows][y cols]
+          if (x < y) {
+            sx = np;
+            sy = 1;
+            return ((int64_t)x * np + y) * BS;
+          }
+          sx = 1;
+          sy = np;
+          return ((int64_t)y * np + x) * BS;
+        };
+        double ta[8], tb[8], qav[8], qb0[8], qb1[8];
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx) {  // k = 16 kx + 4 s + lk: rows of pair A
+          const int x = kx ? hi_a : lo_a;
+          int64_t sx0, sy0, sx1, sy1;
+          const double* p0 = Gin + block_ptr(x, lo_b, sx0, sy0) + lk * sx0 + li * sy0;
+          const double* p1 = Gin + block_ptr(x, hi_b, sx1, sy1) + lk * sx1 + li * sy1;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            ta[4 * kx + s] = p0[4 * s * sx0];
+            tb[4 * kx + s] = p1[4 * s * sx1];
+            qav[4 * kx + s] = qa[(4 * kx + s) * 4 * PS];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          qb0[s] = qb[s * 4 * PS];
+          qb1[s] = qb[s * 4 * PS + 16];
+        }
+        f64x4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {  // Y = T^T Q_A[:, h]  (rows: pair-B index)
+          y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[s], qav[s], y0, 0, 0, 0);
+          y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s], qav[s], y1, 0, 0, 0);
+        }
+        f64x4 r0 = {0.0, 0.0, 0.0, 0.0}, r1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {  // R^T[:, h] = Q_B^T Y
+          const double yb = s < 4 ? y0[s & 3] : y1[s & 3];
+          r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb0[s], yb, r0, 0, 0, 0);
+          r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb1[s], yb, r1, 0, 0, 0);
+        }
+        // r_ib[r] = R[row li of block x][column 4 r + lk of block y_ib]
+        {
+          const int x = h ? hi_a : lo_a;
+          int64_t sx0, sy0, sx1, sy1;
+          double* o0 = Gout + block_ptr(x, lo_b, sx0, sy0) + li * sx0 + lk * sy0;
+          double* o1 = Gout + block_ptr(x, hi_b, sx1, sy1) + li * sx1 + lk * sy1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o0[4 * r * sy0] = r0[r];
+            o1[4 * r * sy1] = r1[r];
+          }
+        }
+        return;
+      }
+      bid -= g_wgs;
+    }
+    const bool is_g = BS != 16 && bid < half * chunks;
     int pa = 0, strip = 0, chunk;
     if (is_g) {
       pa = bid / chunks;
       chunk = bid % chunks;
     } else {
-      bid -= half * chunks;
+      if (BS != 16) bid -= half * chunks;
       strip = bid / chunks;
       chunk = bid % chunks;
     }
@@ -467,7 +567,13 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     const double d_hi = Dcur[(int64_t)kb * PS * PS + (pb * BS + r16) * PS + pb * BS + c16];
     for (int e = tid; e < PS * PS; e += NT) {
       const int a = e / PS, b = e % PS;
-      T[a][b] = Gin[pair_index<BS>(a, a_lo, a_hi) * np + pair_index<BS>(b, b_lo, b_hi)];
+      int64_t ga = pair_index<BS>(a, a_lo, a_hi), gb = pair_index<BS>(b, b_lo, b_hi);
+      if (BS == 16 && ga / BS > gb / BS) {  // block-upper storage: read the mirror image
+        const int64_t tmp = ga;
+        ga = gb;
+        gb = tmp;
+      }
+      T[a][b] = Gin[ga * np + gb];
       QA[a][b] = Qcur[(int64_t)ka * PS * PS + e];
       QB[a][b] = Qcur[(int64_t)kb * PS * PS + e];
     }
@@ -667,31 +773,50 @@ blk_backacc_kernel(const BatchDesc* __restrict__ desc, Work w, const int* __rest
   const int64_t slot = (int64_t)half * PS * PS;
   const int li = lane & 15, lk = lane >> 4;
   const int steps = d.steps_applied, per_sweep = nb - 1;
+  const int per_wave = (half + 3) / 4;  // block pairs of a step handled by this wave: p = wave + 4 i
+  // the rotation block of the NEXT (step, pair) item is fetched into registers while the current one
+  // is multiplied: the L2 / Infinity-Cache latency of the history reads leaves the critical path
+  double2 nx[8];
+  auto fetch = [&](int st, int i) {
+    const int p = wave + 4 * i;
+    if (st < 0 || p >= half) return;
+    const double* src = hist + (int64_t)st * slot + (int64_t)p * PS * PS;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nx[q] = *reinterpret_cast<const double2*>(src + 2 * lane + 128 * q);
+  };
+  fetch(steps - 1, 0);
   for (int st = steps - 1; st >= 0; --st) {
     const int t = st % per_sweep;
-    for (int p = wave; p < half; p += 4) {
-      int lo, hi;
-      pair_blocks(p, t, nb, lo, hi);
-      const double* src = hist + (int64_t)st * slot + (int64_t)p * PS * PS;
+    for (int i = 0; i < per_wave; ++i) {
+      const int p = wave + 4 * i;
+      if (p < half) {
+        int lo, hi;
+        pair_blocks(p, t, nb, lo, hi);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {  // 1024 doubles, 2 per lane and pass
-        const int e = 2 * lane + 128 * i;
-        const double2 v = *reinterpret_cast<const double2*>(src + e);
-        J[e / PS][e % PS] = v.x;
-        J[e / PS][e % PS + 1] = v.y;
+        for (int q = 0; q < 8; ++q) {  // 1024 doubles, 2 per lane and pass
+          const int e = 2 * lane + 128 * q;
+          J[e / PS][e % PS] = nx[q].x;
+          J[e / PS][e % PS + 1] = nx[q].y;
+        }
       }
-      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      if (i + 1 < per_wave) fetch(st, i + 1);
+      else fetch(st - 1, 0);
+      if (p < half) {
+        int lo, hi;
+        pair_blocks(p, t, nb, lo, hi);
+        f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int k0 = 0; k0 < PS; k0 += 4) {
-        const int kr = k0 + lk;  // row of the pair slice this lane feeds as B[k][j]
-        const double yb = Y[(kr < BS ? lo * BS + kr : hi * BS + kr - BS) * LDY + li];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(J[li][kr], yb, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(J[16 + li][kr], yb, acc1, 0, 0, 0);
-      }
+        for (int k0 = 0; k0 < PS; k0 += 4) {
+          const int kr = k0 + lk;  // row of the pair slice this lane feeds as B[k][j]
+          const double yb = Y[(kr < BS ? lo * BS + kr : hi * BS + kr - BS) * LDY + li];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(J[li][kr], yb, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(J[16 + li][kr], yb, acc1, 0, 0, 0);
+        }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {  // rows 0..15 of the slice live in block lo, 16..31 in block hi
-        Y[(lo * BS + lk + 4 * r) * LDY + li] = acc0[r];
-        Y[(hi * BS + lk + 4 * r) * LDY + li] = acc1[r];
+        for (int r = 0; r < 4; ++r) {  // rows 0..15 of the slice live in block lo, 16..31 in block hi
+          Y[(lo * BS + lk + 4 * r) * LDY + li] = acc0[r];
+          Y[(hi * BS + lk + 4 * r) * LDY + li] = acc1[r];
+        }
       }
     }
     __syncthreads();  // the next step regroups the rows
@@ -849,8 +974,12 @@ struct BatchedJacobi {
     }
     const unsigned B = (unsigned)batch;
     // one launch of the step kernel (both block sizes share the argument list)
+    // NDMPS_EIG_DEBUG_ROLE = 1 / 2: launch only the diag / apply role (timing experiments; results are wrong)
+    static const int debug_role = getenv("NDMPS_EIG_DEBUG_ROLE") ? atoi(getenv("NDMPS_EIG_DEBUG_ROLE")) : 0;
     auto step = [&](unsigned gx, int n_diag, int t, int t_next, int full_next, int sweep_next, int first, int solve,
                     int in, int q_cur, int gstep) {
+      if (debug_role == 1 && n_diag > 0) gx = n_diag;
+      if (debug_role == 2 && (int)gx > n_diag && n_diag > 0) { gx -= n_diag; n_diag = 0; }
       if (BS == 32)
         hipLaunchKernelGGL(blk_step_kernel<32>, dim3(gx, B), dim3(1024), lds_bytes, s, desc, w, n_diag, t, t_next,
                            full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg, gstep);
@@ -869,7 +998,7 @@ struct BatchedJacobi {
     sweeps = 0;
     const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
     // history mode: the apply role has no V tiles
-    const int n_apply = half * chunks + (w.hist_mode ? 0 : (np / PS) * chunks);
+    const int n_apply = (BS == 16 ? (half * half + 3) / 4 : half * chunks) + (w.hist_mode ? 0 : (np / PS) * chunks);
     const int steps = nb - 1;  // outer steps per sweep
     if (nb == 2) {
       // every matrix is one block pair: solved in LDS by the diag role, then applied once

@@ -40,6 +40,15 @@ const char* ndmps_last_error(void);
 /* number of HIP devices visible, or a negative code; never initialises a context */
 int ndmps_device_count(void);
 
+/* n HIP streams of the current device on pairwise different hardware queues (as far as the runtime
+ * has queues: *n_independent tells how many are; the rest share).  The runtime binds a stream to one
+ * of its few queues at first use and does not report which, so the binding is measured with a bounded
+ * spin kernel.  For the concurrent volume groups of the batch caller
+ * (reference: evaluation/benchmark.py:58-100 loops over independent tensors one by one; here each
+ * group of the list runs on its own stream). */
+int ndmps_streams_create(int n, void** h_streams, int* n_independent);
+int ndmps_streams_destroy(int n, void* const* h_streams);
+
 /* ---------------------------------------------------------------------------------
  * Index permutation ("reshape stage").
  * Replaces: utils/core.py:6-35,129-168 (gen_encoding_map, never materialised here),
