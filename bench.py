@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (same guide)
 
 
 def parse():
@@ -37,7 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=256, help="edge of the cubic volume")
     ap.add_argument("--chi", type=int, default=64)
     ap.add_argument("--mode", default="Std", choices=["Std", "DCT"])
-    ap.add_argument("--batch", type=int, default=32, help="independent volumes per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="independent volumes per GPU per step")
     ap.add_argument("--groups", type=int, default=4,
                     help="concurrent groups (host thread + HIP stream each) the batch is cut into; "
                          "volumes of a group are encoded in lockstep")
@@ -187,6 +188,61 @@ def main():
         "end_to_end_algorithmic_GBps": args.batch * algo_bytes / (ms_per_step * 1e-3) / 1e9,
     }
 
+    # the kernel with the largest share of device time (profiles/): one outer step of the batched block
+    # Jacobi eigen-solver.  Timed live on 16 Gram matrices of order 512 built from the batch's volumes
+    # (the shape of the three big eigenproblems of every 256^3 / chi = 64 volume), values phase only:
+    # HIP-event time / launches, so the figure includes the per-sweep convergence check.
+    eig_step = None
+    if not args.skip_single and args.size >= 64:
+        import ctypes as C
+
+        lib = _lib.load()
+        nb_eig, n_eig = 16, 512
+        a = torch.stack([xs[j % len(xs)].reshape(n_eig, -1).to(torch.float64) for j in range(nb_eig)])
+        g0 = torch.bmm(a, a.transpose(1, 2)).contiguous()
+        del a
+        vv = torch.empty_like(g0)
+        ww = torch.empty((nb_eig, n_eig), dtype=torch.float64, device=device)
+        nbytes = lib.ndmps_syevj_batched_workspace_bytes(n_eig, nb_eig)
+        wsb = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        sw = (C.c_int * nb_eig)()
+        sizes = _lib.i64_array([n_eig] * nb_eig)
+        times = []
+        for it in range(3):
+            g = g0.clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.ndmps_syevj_batched_values_f64(nb_eig, g.data_ptr(), n_eig * n_eig, sizes, vv.data_ptr(),
+                                                          n_eig * n_eig, ww.data_ptr(), n_eig, 1e-13, wsb.data_ptr(),
+                                                          nbytes, sw, _lib.stream_ptr()))
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+        sweeps = max(sw)
+        nblk = n_eig // 16
+        launches = sweeps * (nblk - 1) + 1
+        step_us = min(times[1:]) * 1e3 / launches
+        pairs = nblk // 2
+        # per launch and matrix: the block-upper half of G is read once and written once (fp64), every
+        # 32x32 rotation block is written once (history) and read by the tiles of its pair row / column
+        step_bytes = nb_eig * (n_eig * n_eig * 8 + 2 * pairs * 32 * 32 * 8)
+        step_flops = nb_eig * (pairs * (pairs - 1) // 2) * 2 * (2 * 32 ** 3)  # two 32^3 products per upper tile
+        eig_step = {
+            "kernel": "blk_step_kernel<16>",
+            "workload": f"{nb_eig} x ({n_eig} x {n_eig}) fp64 Gram matrices in lockstep, one stream",
+            "sweeps": int(sweeps),
+            "launches": int(launches),
+            "launch_us": step_us,
+            "hbm": {"achieved": step_bytes / (step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "bytes_per_launch": step_bytes},
+            "mfma_f64": {"achieved": step_flops / (step_us * 1e-6) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": step_flops / (step_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                         "flops_per_launch": step_flops},
+            "note": "latency-bound when one group runs alone (a step is a dependent chain of ~25 us); with 4 groups "
+                    "in flight the same launches overlap and the aggregate rate is ~2x these figures",
+        }
+        del g0, vv, ww, wsb
+
     line = {
         "metric": "Mvoxels/s compress+reconstruct, 256^3 fp32, bond chi=64; SSIM vs ref",
         "value": value,
@@ -212,6 +268,7 @@ def main():
             "parallelism": f"{world} independent volume shard(s), no data-path collective",
         },
         "roofline": roofline,
+        "roofline_eig_step": eig_step,
         "stages": stages,
         "single_volume": {"ms": single_ms, "Mvoxels_per_s": n_vox / single_ms / 1e3},
         "one_group_of_8": {"ms": group8_ms, "Mvoxels_per_s": min(8, args.batch) * n_vox / group8_ms / 1e3,

@@ -171,6 +171,14 @@ __device__ __forceinline__ int block_sum_int(int v, int* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// offset of G(r, c) in a work matrix.  Block size 16: every 16x16 block is contiguous (2 KB), so an MFMA
+// operand fetch of the register apply path is one 512-byte run and a step streams whole blocks instead
+// of 128-byte pieces of 4 KB-strided rows.  Block size 32 (experimental path): plain row-major.
+__device__ __forceinline__ int64_t g_off(int bs, int np, int64_t r, int64_t c) {
+  if (bs != 16) return r * np + c;
+  return (((r >> 4) * (np >> 4) + (c >> 4)) << 8) + ((r & 15) << 4) + (c & 15);
+}
+
 // position of every index after sorting the diagonal descending (ties by index);
 // one workgroup per index (grid.x = n_max), the count is a block reduction
 __global__ void __launch_bounds__(256) blk_order_kernel(const BatchDesc* __restrict__ desc, Work w) {
@@ -213,7 +221,7 @@ __global__ void __launch_bounds__(256) blk_scatter_kernel(const BatchDesc* __res
   const int64_t total = (int64_t)n * n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / n), c = (int)(e % n);
-    Gp[(int64_t)pos[r] * np + pos[c]] = 0.5 * (G[(int64_t)r * n + c] + G[(int64_t)c * n + r]);
+    Gp[g_off(w.bs, np, pos[r], pos[c])] = 0.5 * (G[(int64_t)r * n + c] + G[(int64_t)c * n + r]);
     if (r == c && !w.hist_mode) Vp[(int64_t)r * np + pos[r]] = 1.0;
   }
 }
@@ -345,16 +353,17 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
     int bid = blockIdx.x - n_diag;
     if constexpr (BS == 16) {
-      // G tiles, register-only: one WAVE = one 16-column half of one upper tile (pa < pb), no LDS
-      // and no barrier.  With R = Q_A^T T Q_B, the wave computes the half  R^T[:, h] = Q_B^T (T^T Q_A[:, h]):
-      // the accumulator of the first product (row 4r + lk, column li) IS the B operand of the second
-      // (k = 4s + lk), so nothing is transposed or staged; all operands are read from global / L2
-      // straight into MFMA layout (128-byte row segments).  half^2 wave items per matrix:
-      // `half` copies of the prepared diagonal tiles + 2 per upper tile.
-      const int g_wgs = (half * half + 3) >> 2;
+      // G tiles, register-only: one WAVE = one upper tile (pa < pb), no LDS and no barrier.  With
+      // R = Q_A^T T Q_B, the wave computes, for each 16-column half h of pair A,
+      // R^T[:, h] = Q_B^T (T^T Q_A[:, h]): the accumulator of the first product (row 4r + lk, column li)
+      // IS the B operand of the second (k = 4s + lk), so nothing is transposed or staged; all operands
+      // are read from global / L2 straight into MFMA layout.  Wave items per matrix: `half` copies of
+      // the prepared diagonal tiles + one per upper tile.
+      const int n_items = half + half * (half - 1) / 2;
+      const int g_wgs = (n_items + 3) >> 2;
       if (bid < g_wgs) {
         const int wid = __builtin_amdgcn_readfirstlane(bid * 4 + wave);
-        if (wid >= half * half) return;
+        if (wid >= n_items) return;
         double* Gout = w.G[in ^ 1] + mat;
         const int li = lane & 15, lk = lane >> 4;
         if (wid < half) {  // diagonal tile: prepared (already rotated) by the diag role
@@ -364,13 +373,12 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const int e = 2 * lane + 128 * q;
-            *reinterpret_cast<double2*>(Gout + pair_index<BS>(e / PS, lo, hi) * np + pair_index<BS>(e % PS, lo, hi)) =
+            *reinterpret_cast<double2*>(Gout + g_off(BS, np, pair_index<BS>(e / PS, lo, hi), pair_index<BS>(e % PS, lo, hi))) =
                 *reinterpret_cast<const double2*>(dsrc + e);
           }
           return;
         }
-        const int u2 = wid - half, h = u2 & 1;
-        int u = u2 >> 1, pa = 0;
+        int u = wid - half, pa = 0;
         while (u >= half - 1 - pa) {
           u -= half - 1 - pa;
           ++pa;
@@ -379,24 +387,23 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
         int lo_a, hi_a, lo_b, hi_b;
         pair_blocks(pa, t, nb, lo_a, hi_a);
         pair_blocks(pb, t, nb, lo_b, hi_b);
-        const double* qa = Qcur + (int64_t)pa * PS * PS + lk * PS + 16 * h + li;
+        const double* qa = Qcur + (int64_t)pa * PS * PS + lk * PS + li;
         const double* qb = Qcur + (int64_t)pb * PS * PS + lk * PS + li;
         // G is symmetric and only its block-upper half is kept (16x16 block (x, y) with x < y; the
         // diagonal blocks travel in the prepared diagonal tiles): a block with x > y is read, and
-        // written, through its mirror image -- 32-byte pieces instead of 128-byte rows, same bytes.
-        // That halves the write traffic of a step, which is what bounds the kernel once several
-        // matrices are in flight (measured ~4 TB/s of G traffic).
+        // written, through its mirror image -- 32-byte pieces instead of 512-byte runs, same bytes.
+        // That halves the write traffic of a step.
         auto block_ptr = [&](int x, int y, int64_t& sx, int64_t& sy) -> int64_t {  // &G[x rows][y cols]
           if (x < y) {
-            sx = np;
+            sx = BS;
             sy = 1;
-            return ((int64_t)x * np + y) * BS;
+            return ((int64_t)x * nb + y) * (BS * BS);
           }
           sx = 1;
-          sy = np;
-          return ((int64_t)y * np + x) * BS;
+          sy = BS;
+          return ((int64_t)y * nb + x) * (BS * BS);
         };
-        double ta[8], tb[8], qav[8], qb0[8], qb1[8];
+        double ta[8], tb[8], qb0[8], qb1[8];
 #pragma unroll
         for (int kx = 0; kx < 2; ++kx) {  // k = 16 kx + 4 s + lk: rows of pair A
           const int x = kx ? hi_a : lo_a;
@@ -407,7 +414,6 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
           for (int s = 0; s < 4; ++s) {
             ta[4 * kx + s] = p0[4 * s * sx0];
             tb[4 * kx + s] = p1[4 * s * sx1];
-            qav[4 * kx + s] = qa[(4 * kx + s) * 4 * PS];
           }
         }
 #pragma unroll
@@ -415,21 +421,25 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
           qb0[s] = qb[s * 4 * PS];
           qb1[s] = qb[s * 4 * PS + 16];
         }
-        f64x4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {  // Y = T^T Q_A[:, h]  (rows: pair-B index)
-          y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[s], qav[s], y0, 0, 0, 0);
-          y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s], qav[s], y1, 0, 0, 0);
-        }
-        f64x4 r0 = {0.0, 0.0, 0.0, 0.0}, r1 = {0.0, 0.0, 0.0, 0.0};
+        for (int h = 0; h < 2; ++h) {
+          double qav[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {  // R^T[:, h] = Q_B^T Y
-          const double yb = s < 4 ? y0[s & 3] : y1[s & 3];
-          r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb0[s], yb, r0, 0, 0, 0);
-          r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb1[s], yb, r1, 0, 0, 0);
-        }
-        // r_ib[r] = R[row li of block x][column 4 r + lk of block y_ib]
-        {
+          for (int s = 0; s < 8; ++s) qav[s] = qa[s * 4 * PS + 16 * h];
+          f64x4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {  // Y = T^T Q_A[:, h]  (rows: pair-B index)
+            y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[s], qav[s], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s], qav[s], y1, 0, 0, 0);
+          }
+          f64x4 r0 = {0.0, 0.0, 0.0, 0.0}, r1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {  // R^T[:, h] = Q_B^T Y
+            const double yb = s < 4 ? y0[s & 3] : y1[s & 3];
+            r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb0[s], yb, r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb1[s], yb, r1, 0, 0, 0);
+          }
+          // r_ib[r] = R[row li of block x][column 4 r + lk of block y_ib]
           const int x = h ? hi_a : lo_a;
           int64_t sx0, sy0, sx1, sy1;
           double* o0 = Gout + block_ptr(x, lo_b, sx0, sy0) + li * sx0 + lk * sy0;
@@ -548,7 +558,7 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     for (int e = tid; e < PS * PS; e += NT) {
       const int a = e / PS, b = e % PS;
       const int64_t ga = pair_index<BS>(a, lo, hi), gb = pair_index<BS>(b, lo, hi);
-      S0[a][b] = 0.5 * (Gin[ga * np + gb] + Gin[gb * np + ga]);
+      S0[a][b] = 0.5 * (Gin[g_off(BS, np, ga, gb)] + Gin[g_off(BS, np, gb, ga)]);
       Q[a][b] = (a == b) ? 1.0 : 0.0;
     }
     __syncthreads();
@@ -573,7 +583,7 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
         ga = gb;
         gb = tmp;
       }
-      T[a][b] = Gin[ga * np + gb];
+      T[a][b] = Gin[g_off(BS, np, ga, gb)];
       QA[a][b] = Qcur[(int64_t)ka * PS * PS + e];
       QB[a][b] = Qcur[(int64_t)kb * PS * PS + e];
     }
@@ -692,10 +702,10 @@ __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restri
   const double* G = w.G[d.final_buf] + (int64_t)blockIdx.y * np * np;
   const int i = blockIdx.x;
   if (i >= n) return;
-  const double wi = G[(int64_t)i * np + i];
+  const double wi = G[g_off(w.bs, np, i, i)];
   int rk = 0;
   for (int j = threadIdx.x; j < n; j += 256) {
-    const double wj = G[(int64_t)j * np + j];
+    const double wj = G[g_off(w.bs, np, j, j)];
     rk += (wj > wi) || (wj == wi && j < i);
   }
   rk = block_sum_int(rk, red);
@@ -998,7 +1008,8 @@ struct BatchedJacobi {
     sweeps = 0;
     const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
     // history mode: the apply role has no V tiles
-    const int n_apply = (BS == 16 ? (half * half + 3) / 4 : half * chunks) + (w.hist_mode ? 0 : (np / PS) * chunks);
+    const int n_apply = (BS == 16 ? (half + half * (half - 1) / 2 + 3) / 4 : half * chunks) +
+                        (w.hist_mode ? 0 : (np / PS) * chunks);
     const int steps = nb - 1;  // outer steps per sweep
     if (nb == 2) {
       // every matrix is one block pair: solved in LDS by the diag role, then applied once
