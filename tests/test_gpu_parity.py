@@ -586,6 +586,44 @@ def test_from_tensors_equals_from_tensor_one_by_one():
     assert NDMPS.from_tensors([]) == []
 
 
+def test_streams_create_returns_usable_distinct_streams():
+    lib = _lib.load()
+    raw = (C.c_void_p * 4)()
+    found = C.c_int(-1)
+    _lib.check(lib.ndmps_streams_create(4, raw, C.byref(found)))
+    assert 1 <= found.value <= 4
+    assert len({int(raw[i]) for i in range(4)}) == 4
+    x = torch.arange(1000, device=DEV, dtype=torch.float32)
+    torch.cuda.synchronize()
+    for i in range(4):  # the handles are ordinary HIP streams
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(raw[i]))):
+            y = x * 2
+        torch.cuda.synchronize()
+        assert float(y.sum()) == float(x.sum()) * 2
+    _lib.check(lib.ndmps_streams_destroy(4, raw))
+    with pytest.raises(ValueError):
+        _lib.check(lib.ndmps_streams_create(0, raw, None))
+
+
+def test_concurrent_groups_equal_one_by_one():
+    """encode_decode_concurrent (groups on their own host threads and streams) returns, in input
+    order, exactly what from_tensor / to_tensor give volume by volume; second call reuses the streams."""
+    from imgcompressionmps_amd.core import batch as batch_mod
+
+    vols = [torch.from_numpy(synthetic_mri((32, 32, 32), seed=20 + s)).to(DEV) for s in range(7)]
+    for groups in (3, 1):
+        objs, recs = batch_mod.encode_decode_concurrent(vols, groups=groups, max_bond=10)
+        torch.cuda.synchronize()
+        assert len(objs) == len(recs) == 7
+        for v, ob, rec in zip(vols, objs, recs):
+            single = NDMPS.from_tensor(v, max_bond=10)
+            assert ob.bond_sizes() == single.bond_sizes()
+            assert torch.equal(rec, single.to_tensor(as_torch=True))
+    assert batch_mod.group_streams(3) is batch_mod.group_streams(3)
+    objs, recs = batch_mod.encode_decode_concurrent(vols[:2], groups=4, max_bond=10, reconstruct=False)
+    assert recs is None and len(objs) == 2
+
+
 def test_minmax_many_matches_single():
     ts = [torch.randn(n, device=DEV) for n in (1, 17, 4096, 100003)]
     got = hft.minmax_many(ts)
