@@ -28,9 +28,9 @@ def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < extra else 0)))
 
 
-def conv_to_mps(tensor_list: Sequence, mode: str = "Std", norm: bool = False, max_bond=None,
+def conv_to_mps(tensor_list: Sequence, mode: str = "DCT", norm: bool = False, max_bond=None,
                 cutoff: float = 1e-10, device=None):
-    """benchmark.py:58-77: encode every tensor of the (local) list."""
+    """benchmark.py:58-77: encode every tensor of the (local) list (default mode "DCT" as there)."""
     from .ndmps import NDMPS
 
     return [NDMPS.from_tensor(t, norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff, device=device)
@@ -190,6 +190,46 @@ def run_benchmark(mps_list, original_tensors_list, cutoff_list, verbose=True):
         elif key != "bond_dims" and isinstance(results[key][0], (list, np.ndarray)) and np.ndim(results[key][0]) > 0:
             results[key] = np.array(results[key]).T
     return results
+
+
+def run_full_benchmark(dataset_path, cutoff_list, result_file, datatype="MRI", mode="DCT", start=0, end=-1,
+                       ending=".gz", shape=None):
+    """benchmark.py:197-242: load every file of a dataset directory, encode, run the cutoff sweep and
+    write the result JSON (same keys, same order; relative result paths land under
+    ``src/evaluation/results`` like the reference's).  Returns the result dictionary."""
+    import json
+    from pathlib import Path
+
+    from ..utils.loaders import find_specific_files, get_shapes, load_tensors, mri_to_slices
+
+    dataset_path = Path(dataset_path)
+    result_path = Path(result_file)
+    if not result_path.is_absolute() and not str(result_path).startswith("src/evaluation/results"):
+        result_path = Path("src/evaluation/results") / result_path
+    files = find_specific_files(dataset_path, ending)
+    files = files[start:] if end == -1 else files[start:end]
+    if not files:
+        raise FileNotFoundError(f"No files with extension {ending} found in {dataset_path}")
+    data_list, bitsize_list = load_tensors(files, ending, shape)
+    if datatype == "MRI_Slice":
+        data_list, bitsize_list = mri_to_slices(data_list, bitsize_list)
+    mps_list = conv_to_mps(data_list, mode)
+    print("Starting benchmark...")
+    metrics = run_benchmark(mps_list, data_list, cutoff_list)
+    print(f"Saving results to {result_path}")
+    result_dict = {
+        "datatype": datatype,
+        "mode": mode,
+        "files": files,
+        "cutoff_list": cutoff_list.tolist(),
+        "bitsize_list": bitsize_list,
+        "shapes": get_shapes(data_list),
+        **{k: v.tolist() if hasattr(v, "tolist") else v for k, v in metrics.items()},
+    }
+    result_path.parent.mkdir(parents=True, exist_ok=True)
+    with open(result_path, "w") as f:
+        json.dump(result_dict, f, indent=2)
+    return result_dict
 
 
 # ------------------------------------------------------------------------ collectives

@@ -1,0 +1,155 @@
+"""Serialised form of an NDMPS: a byte string / file that holds everything
+``to_tensor`` needs, so a compressed volume can leave the process.
+
+The reference never persists an MPS; it only measures what one *would* take on disk by
+gzip-compressing every quantised core in memory (core/ndmps.py:209-234, one gzip member per core,
+default level) and by counting ``number_elements * bits`` (:259-277).  The container below stores
+exactly those gzip members, in site order, so its payload size IS ``get_bytesize_on_disk(dtype)``:
+
+    magic "NDMPS\\x01\\0\\0" | u32 version | u32 header bytes | header (JSON, utf-8) | members
+
+Header: shape, mode, norm flag, norm_value, dim, qubit_size (site dims), bonds, storage dtype
+("uint8" / "uint16" = the reference's ``scale_to_dtype`` min-max quantisation, filetools.py:20-39,
+truncating cast; "float32" = lossless cores), per-core (min, max) used by ``scale_back``, per-member
+byte counts.  The factor lists are a pure function of ``shape`` (utils/core.py:79-126) and are rebuilt on
+load.  Quantisation and de-quantisation run on the device (csrc/reduce.hip); gzip runs on the host, as
+in the reference.
+"""
+from __future__ import annotations
+
+import gzip
+import io
+import json
+import struct
+
+import numpy as np
+
+from ..utils import filetools as _ft
+
+MAGIC = b"NDMPS\x01\x00\x00"
+VERSION = 1
+_DTYPES = {"uint8": np.uint8, "uint16": np.uint16, "float32": np.float32}
+
+
+def _gzip_member(raw: bytes) -> bytes:
+    buf = io.BytesIO()
+    with gzip.GzipFile(fileobj=buf, mode="wb", mtime=0) as gz:  # mtime fixed: byte-reproducible files
+        gz.write(raw)
+    return buf.getvalue()
+
+
+def dumps(obj, dtype=np.uint16) -> bytes:
+    """Serialise ``obj`` (an NDMPS made by ``from_tensor``) with cores stored as ``dtype``
+    (np.uint8 / np.uint16: the reference's quantisation; np.float32: exact cores)."""
+    if obj._shape is None:
+        raise ValueError("this NDMPS was not created by from_tensor; the tensor shape is unknown")
+    name = np.dtype(dtype).name
+    if name not in _DTYPES:
+        raise ValueError(f"Unsupported dtype {dtype!r}: cores are stored as uint8, uint16 or float32")
+    cores = obj.mps.cores
+    members, bounds = [], []
+    if name == "float32":
+        for c in cores:
+            members.append(_gzip_member(c.cpu().numpy().tobytes()))
+            bounds.append([0.0, 0.0])
+    else:
+        # the (min, max) scale_to_dtype derives from the data is what scale_back must be given
+        mm = _ft.minmax_many(cores)
+        for c, (lo, hi) in zip(cores, mm):
+            q = _ft.scale_to_dtype(c, _DTYPES[name])
+            members.append(_gzip_member(_ft.to_numpy_uint(q, _DTYPES[name]).tobytes()))
+            bounds.append([lo, hi])
+    header = {
+        "version": VERSION,
+        "shape": [int(s) for s in obj._shape],
+        "mode": obj.mode,
+        "norm": bool(obj.norm),
+        "norm_value": None if obj.norm_value is None else float(obj.norm_value),
+        "dim": int(obj.dim),
+        "qubit_size": [int(q) for q in obj.qubit_size],
+        "bonds": [int(b) for b in obj.mps.bonds],
+        "dtype": name,
+        "bounds": bounds,
+        "member_bytes": [len(m) for m in members],
+    }
+    hb = json.dumps(header, separators=(",", ":")).encode("utf-8")
+    return b"".join([MAGIC, struct.pack("<II", VERSION, len(hb)), hb] + members)
+
+
+def payload_bytes(data: bytes) -> int:
+    """Size of the gzip members of a serialised NDMPS (= ``get_bytesize_on_disk`` for uint dtypes)."""
+    return sum(_header(data)[0]["member_bytes"])
+
+
+def _header(data: bytes):
+    if len(data) < 16 or data[:8] != MAGIC:
+        raise ValueError("not an NDMPS container (bad magic)")
+    version, hlen = struct.unpack("<II", data[8:16])
+    if version != VERSION:
+        raise ValueError(f"unsupported NDMPS container version {version}")
+    if 16 + hlen > len(data):
+        raise ValueError("truncated NDMPS container (header)")
+    header = json.loads(data[16:16 + hlen].decode("utf-8"))
+    return header, 16 + hlen
+
+
+def loads(data: bytes, device=None):
+    """Rebuild the NDMPS on ``device`` (default: the current HIP device).  Quantised cores are
+    scaled back exactly like ``compress_to_dtype(replace=True)`` leaves them (filetools.py:29-39)."""
+    import torch
+
+    from .. import _lib
+    from .mps import DeviceMPS
+    from .ndmps import NDMPS, _plan_for
+
+    header, off = _header(data)
+    _lib.require_device()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    shape = tuple(header["shape"])
+    name = header["dtype"]
+    if name not in _DTYPES:
+        raise ValueError(f"unsupported core dtype {name!r}")
+    bonds, dims = header["bonds"], header["qubit_size"]
+    if len(bonds) != len(dims) + 1 or len(header["member_bytes"]) != len(dims):
+        raise ValueError("inconsistent NDMPS container header")
+    with torch.cuda.device(device):
+        plan = _plan_for(shape, device.index or 0)
+        if [int(q) for q in plan.qubit_size] != [int(d) for d in dims]:
+            raise ValueError("site dimensions in the container do not match the factorisation of its shape")
+        cores = []
+        for i, nbytes in enumerate(header["member_bytes"]):
+            if off + nbytes > len(data):
+                raise ValueError("truncated NDMPS container (payload)")
+            raw = gzip.decompress(data[off:off + nbytes])
+            off += nbytes
+            cshape = (bonds[i], dims[i], bonds[i + 1])
+            want = int(np.prod(cshape)) * np.dtype(_DTYPES[name]).itemsize
+            if len(raw) != want:
+                raise ValueError(f"core {i}: {len(raw)} bytes, expected {want}")
+            arr = np.frombuffer(raw, dtype=_DTYPES[name]).reshape(cshape)
+            if name == "float32":
+                cores.append(torch.from_numpy(arr.copy()).to(device))
+            else:
+                # torch has no uint16: same bytes as int16 storage (what scale_back reads)
+                host = arr.view(np.int16) if name == "uint16" else arr
+                q = torch.from_numpy(host.copy()).to(device)
+                lo, hi = header["bounds"][i]
+                cores.append(_ft.scale_back(q, lo, hi, _DTYPES[name]))
+        obj = NDMPS(DeviceMPS(cores), plan.qubit_size.copy(), None, [[0.0, 0.0]] * len(cores), header["norm"],
+                    header["norm_value"], header["mode"], header["dim"])
+        obj._shape = shape
+        obj.update_boundary_list()
+    return obj
+
+
+def save(obj, path, dtype=np.uint16) -> int:
+    """Write the container to ``path``; returns the file size in bytes."""
+    data = dumps(obj, dtype)
+    with open(path, "wb") as f:
+        f.write(data)
+    return len(data)
+
+
+def load(path, device=None):
+    with open(path, "rb") as f:
+        return loads(f.read(), device)

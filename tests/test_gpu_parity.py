@@ -846,3 +846,64 @@ def test_run_benchmark_matches_an_oracle_driven_loop():
         batch.benchmark_metric(gpu_list, None, metric="nope")
     with pytest.raises(IndexError):
         batch.benchmark_metric(gpu_list, [1], metric="ssim")
+
+
+# ------------------------------------------------------------------- 8f#4: container and driver
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8, np.float32])
+def test_container_round_trip(dtype, tmp_path):
+    """dumps / loads: the payload is the reference's per-core gzip members (ndmps.py:209-234), the
+    reloaded object reconstructs exactly what compress_to_dtype(replace=True) leaves."""
+    from imgcompressionmps_amd.core import codec
+
+    x = synthetic_mri((32, 32, 32), seed=31)
+    for mode in ("Std", "DCT"):
+        obj = NDMPS.from_tensor(x, mode=mode, max_bond=12)
+        blob = codec.dumps(obj, dtype)
+        again = codec.loads(blob)
+        assert again.bond_sizes() == obj.bond_sizes() and again.mode == mode and again.dim == 3
+        assert again.norm_value == obj.norm_value and tuple(again.qubit_size) == tuple(obj.qubit_size)
+        if dtype is np.float32:
+            assert np.array_equal(again.to_tensor(), obj.to_tensor())
+        else:
+            assert codec.payload_bytes(blob) == obj.get_bytesize_on_disk(dtype)
+            twin = copy.deepcopy(obj)
+            twin.compress_to_dtype(dtype, replace=True)
+            assert np.array_equal(again.to_tensor(), twin.to_tensor())
+            for a, b in zip(again.mps.cores, twin.mps.cores):
+                assert torch.equal(a, b)
+        assert np.array_equal(again.boundary_list, np.array([list(v) for v in hft.minmax_many(again.mps.cores)]))
+    path = tmp_path / "vol.ndmps"
+    size = codec.save(obj, path, np.uint16)
+    assert path.stat().st_size == size
+    assert np.array_equal(codec.load(path).to_tensor(), codec.loads(codec.dumps(obj, np.uint16)).to_tensor())
+    # a uint16 container of a chi = 12 volume is far smaller than the volume
+    assert size < x.nbytes / 8
+    with pytest.raises(ValueError):
+        codec.dumps(obj, np.int32)
+    with pytest.raises(ValueError):
+        codec.loads(blob[:-5])
+
+
+def test_run_full_benchmark_writes_the_reference_schema(tmp_path):
+    """benchmark.py:197-242 over a directory of .npz files ("sequence" key): result keys, order and shapes."""
+    import json
+
+    from imgcompressionmps_amd.core import batch
+
+    for s in (1, 2):
+        np.savez(tmp_path / f"clip{s}.npz", sequence=(synthetic_mri((16, 32, 32), seed=s) * 255).astype(np.uint8))
+    out = tmp_path / "res" / "r.json"
+    cut = np.array([0.05, 0.2])
+    res = batch.run_full_benchmark(tmp_path, cut, out, datatype="Video", mode="DCT", ending=".npz", shape=(8, 32, 32))
+    disk = json.loads(out.read_text())
+    assert list(disk) == ["datatype", "mode", "files", "cutoff_list", "bitsize_list", "shapes", "ssim",
+                          "compression_ratio", "bond_dims", "psnr", "fidelity", "storage", "gzip_bytes", "gzip_ratio"]
+    assert disk["bitsize_list"] == [8, 8] and disk["shapes"] == [[8, 32, 32]] * 2 and disk["cutoff_list"] == [0.05, 0.2]
+    assert np.array(disk["ssim"]).shape == (2, 3) and len(disk["bond_dims"]) == 3
+    assert sorted(disk["files"]) == sorted(str(tmp_path / f"clip{s}.npz") for s in (1, 2))
+    ratios = np.array(disk["compression_ratio"])
+    assert np.all(np.diff(ratios, axis=1) <= 0)  # every cutoff shrinks (or keeps) the MPS
+    assert np.all(np.array(disk["ssim"])[:, 0] > 0.999)
+    assert res["datatype"] == "Video"
+    with pytest.raises(FileNotFoundError):
+        batch.run_full_benchmark(tmp_path, cut, out, ending=".gz")
