@@ -24,6 +24,7 @@ import contextlib
 import ctypes as C
 import gzip
 import io
+import threading
 
 import numpy as np
 
@@ -110,21 +111,28 @@ class _Plan:
             pass
 
 
+_CACHE_LOCK = threading.Lock()  # concurrent groups (core/batch.py) reach the caches from several host threads
+
+
 def _plan_for(shape, device_index):
     key = (tuple(int(s) for s in shape), device_index)
-    if key not in _PLAN_CACHE:
-        _PLAN_CACHE[key] = _Plan(shape)
-    return _PLAN_CACHE[key]
+    with _CACHE_LOCK:
+        if key not in _PLAN_CACHE:
+            _PLAN_CACHE[key] = _Plan(shape)  # plan tables are uploaded with synchronous copies
+        return _PLAN_CACHE[key]
 
 
 def _dct_basis(n, device):
     torch = _torch()
     key = (int(n), str(device))
-    if key not in _DCT_CACHE:
-        basis = torch.empty((n, n), dtype=torch.float32, device=device)
-        _lib.check(_lib.load().ndmps_dct_basis_f32(basis.data_ptr(), n, _lib.stream_ptr()))
-        _DCT_CACHE[key] = basis
-    return _DCT_CACHE[key]
+    with _CACHE_LOCK:
+        if key not in _DCT_CACHE:
+            basis = torch.empty((n, n), dtype=torch.float32, device=device)
+            _lib.check(_lib.load().ndmps_dct_basis_f32(basis.data_ptr(), n, _lib.stream_ptr()))
+            # the basis is shared by every stream from now on: finish the fill before publishing it
+            torch.cuda.current_stream().synchronize()
+            _DCT_CACHE[key] = basis
+        return _DCT_CACHE[key]
 
 
 class NDMPS:

@@ -32,6 +32,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -973,19 +975,27 @@ struct BatchedJacobi {
     const int np = w.np, nb = w.nb, half = nb / 2;
     const int BS = w.bs, PS = 2 * BS, kTilesPerWg = tiles_per_wg(BS);
     const size_t lds_bytes = (size_t)4 * PS * (PS + 1) * sizeof(double);
-    static bool attr_set = false;  // 133 KB of dynamic LDS needs an explicit opt-in (once per process)
-    if (!attr_set) {
-      NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_step_kernel<32>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 65 * 8));
-      NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (kHistMaxNp * 17 + 4 * 32 * 33) * 8));
-      attr_set = true;
-    }
+    // > 64 KB of dynamic LDS needs an explicit opt-in; once per process, and concurrent groups make
+    // their first call from several host threads at the same moment
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_step_kernel<32>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 65 * 8);
+      if (attr_err == hipSuccess)
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (kHistMaxNp * 17 + 4 * 32 * 33) * 8);
+    });
+    NDMPS_CHECK_HIP(attr_err);
     const unsigned B = (unsigned)batch;
     // one launch of the step kernel (both block sizes share the argument list)
     // NDMPS_EIG_DEBUG_ROLE = 1 / 2: launch only the diag / apply role (timing experiments; results are wrong)
-    static const int debug_role = getenv("NDMPS_EIG_DEBUG_ROLE") ? atoi(getenv("NDMPS_EIG_DEBUG_ROLE")) : 0;
+    static const int debug_role = [] {
+      const int v = getenv("NDMPS_EIG_DEBUG_ROLE") ? atoi(getenv("NDMPS_EIG_DEBUG_ROLE")) : 0;
+      if (v) fprintf(stderr, "libndmps_hip: NDMPS_EIG_DEBUG_ROLE=%d -- timing experiment, eigen results are WRONG\n", v);
+      return v;
+    }();
     auto step = [&](unsigned gx, int n_diag, int t, int t_next, int full_next, int sweep_next, int first, int solve,
                     int in, int q_cur, int gstep) {
       if (debug_role == 1 && n_diag > 0) gx = n_diag;

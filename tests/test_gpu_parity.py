@@ -620,6 +620,10 @@ def test_concurrent_groups_equal_one_by_one():
             assert ob.bond_sizes() == single.bond_sizes()
             assert torch.equal(rec, single.to_tensor(as_torch=True))
     assert batch_mod.group_streams(3) is batch_mod.group_streams(3)
+    objs, recs = batch_mod.encode_decode_concurrent(vols, groups=4, mode="DCT", max_bond=10)
+    torch.cuda.synchronize()
+    for v, rec in zip(vols, recs):
+        assert torch.equal(rec, NDMPS.from_tensor(v, mode="DCT", max_bond=10).to_tensor(as_torch=True))
     objs, recs = batch_mod.encode_decode_concurrent(vols[:2], groups=4, max_bond=10, reconstruct=False)
     assert recs is None and len(objs) == 2
 
