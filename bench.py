@@ -234,7 +234,10 @@ def main():
             "launches": int(launches),
             "launch_us": step_us,
             "hbm": {"achieved": step_bytes / (step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "bytes_per_launch": step_bytes},
+                    "frac": step_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "bytes_per_launch": step_bytes,
+                    # rocprofv3 PMC passes on this very workload (tools/role_probe.py 16 512): FETCH_SIZE
+                    # 16 596 KB + WRITE_SIZE 20 436 KB per launch (profiles/r01_g_pmc_step_kernel_*.txt)
+                    "traffic": (16596 + 20436) * 1024.0},
             "mfma_f64": {"achieved": step_flops / (step_us * 1e-6) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": step_flops / (step_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                          "flops_per_launch": step_flops},
