@@ -911,3 +911,31 @@ def test_run_full_benchmark_writes_the_reference_schema(tmp_path):
     assert res["datatype"] == "Video"
     with pytest.raises(FileNotFoundError):
         batch.run_full_benchmark(tmp_path, cut, out, ending=".gz")
+
+
+def test_rccl_gathers_of_real_cores_single_rank():
+    """the optional gathers with device tensors over the nccl (= RCCL) backend.  One GPU box:
+    world size 1 (the multi-rank exchange pattern is covered with gloo in tests/test_batch_sharding.py)."""
+    import socket
+
+    import torch.distributed as dist
+
+    from imgcompressionmps_amd.core import batch
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        vols = [torch.from_numpy(synthetic_mri((16, 16, 16), seed=40 + s)).to(DEV) for s in range(3)]
+        objs = NDMPS.from_tensors(vols, max_bond=6)
+        gathered = batch.all_gather_cores([o.mps.cores for o in objs])
+        assert len(gathered) == 3
+        for o, cores in zip(objs, gathered):
+            assert all(c.is_cuda and torch.equal(a, c) for a, c in zip(o.mps.cores, cores))
+        recs = [o.to_tensor(as_torch=True) for o in objs]
+        allv = batch.all_gather_volumes(recs, 3)
+        assert all(torch.equal(a, b) for a, b in zip(recs, allv))
+    finally:
+        dist.destroy_process_group()
