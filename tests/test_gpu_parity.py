@@ -568,6 +568,57 @@ def test_batched_eigensolver_mixed_sizes():
         assert np.abs(mats[b] @ v - v * w[None, :]).max() <= 1e-13 * ref[0]
 
 
+@pytest.mark.parametrize("sizes", [[300, 512, 257], [900, 1000]])
+def test_batched_eigensolver_large_and_two_phase(sizes):
+    """Orders 257..512 in a batch run in history mode (rotation blocks recorded, eigenvectors replayed on
+    the wanted columns); orders above 896 keep the in-loop V update.  Both against LAPACK, full
+    vectors and the two-phase form with only k leading columns."""
+    lib = _lib.load()
+    nmax = max(sizes)
+    rng = np.random.default_rng(sum(sizes))
+    mats = []
+    g_all = np.zeros((len(sizes), nmax * nmax))
+    for b, n in enumerate(sizes):
+        a = rng.standard_normal((n + 9, n)) * np.logspace(0, -5, n)[None, :]
+        q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        g = q @ (a.T @ a) @ q.T  # graded spectrum, dense eigenvectors
+        g = 0.5 * (g + g.T)
+        mats.append(g)
+        g_all[b, : n * n] = g.reshape(-1)
+    nbytes = lib.ndmps_syevj_batched_workspace_bytes(nmax, len(sizes))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    tw = torch.zeros((len(sizes), nmax), dtype=torch.float64, device=DEV)
+    sweeps = C.c_int()
+    tg = dev(g_all)
+    tv = torch.zeros_like(tg)
+    _lib.check(lib.ndmps_syevj_batched_f64(len(sizes), tg.data_ptr(), nmax * nmax, _lib.i64_array(sizes),
+                                           tv.data_ptr(), nmax * nmax, tw.data_ptr(), nmax, ws.data_ptr(), nbytes,
+                                           C.byref(sweeps), sp()))
+    full = []
+    for b, n in enumerate(sizes):
+        w = tw[b, :n].cpu().numpy()
+        v = tv[b, : n * n].cpu().numpy().reshape(n, n)
+        ref = np.linalg.eigvalsh(mats[b])[::-1]
+        assert np.all(np.diff(w) <= 0)
+        assert np.abs(w - ref).max() <= 2e-15 * n * ref[0]  # LAPACK's own backward error is n eps |G|
+        assert np.abs(v.T @ v - np.eye(n)).max() <= 2e-15 * n
+        assert np.abs(mats[b] @ v - v * w[None, :]).max() <= 2e-15 * n * ref[0]
+        full.append(v)
+    # two-phase: values, then k leading vectors only (identical to the leading columns of the full solve)
+    ks = [max(1, n // 8) for n in sizes]
+    tg = dev(g_all)
+    tv2 = torch.zeros_like(tg)
+    _lib.check(lib.ndmps_syevj_batched_values_f64(len(sizes), tg.data_ptr(), nmax * nmax, _lib.i64_array(sizes),
+                                                  tv2.data_ptr(), nmax * nmax, tw.data_ptr(), nmax, 1e-15,
+                                                  ws.data_ptr(), nbytes, C.byref(sweeps), sp()))
+    _lib.check(lib.ndmps_syevj_batched_vectors_f64(len(sizes), tg.data_ptr(), nmax * nmax, _lib.i64_array(sizes),
+                                                   tv2.data_ptr(), nmax * nmax, tw.data_ptr(), nmax,
+                                                   _lib.i64_array(ks), ws.data_ptr(), nbytes, sp()))
+    for b, (n, k) in enumerate(zip(sizes, ks)):
+        v = tv2[b, : n * n].cpu().numpy().reshape(n, n)[:, :k]
+        assert np.array_equal(v, full[b][:, :k])
+
+
 def test_from_tensors_equals_from_tensor_one_by_one():
     vols = [synthetic_mri((32, 32, 32), seed=s) for s in (1, 2, 3)]
     vols[1] = vols[1] * 0.25  # different scales and spectra inside one batch
