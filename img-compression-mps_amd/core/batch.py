@@ -73,7 +73,8 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
     volumes in lockstep (``NDMPS.from_tensors``).  The eigen-solver phases of a group keep only a
     fraction of the chip busy, so several groups in flight overlap them with each other's
     streaming phases (measured on MI355X: 8 volumes in flight 3.1, 16 -> 4.5, 32 -> 5.3 Gvoxel/s).
-    Returns (list of NDMPS, list of reconstructions or None) in input order."""
+    Returns (list of NDMPS, list of reconstructions or None) in input order; every group's work has
+    completed on the device when the call returns."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
 
@@ -97,9 +98,10 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
             objs = NDMPS.from_tensors([tensor_list[i] for i in idx], norm=norm, mode=mode, max_bond=max_bond,
                                       cutoff=cutoff)
             recs = [o.to_tensor(as_torch=True) for o in objs] if reconstruct else None
-            done = torch.cuda.Event()
-            done.record(stream)
-        return objs, recs, done
+        # host-side completion: a device-side wait on the caller's stream would sit in whichever
+        # hardware queue that stream shares with a group and hold that group's next launches behind it
+        stream.synchronize()
+        return objs, recs
 
     own_pool = pool is None
     if own_pool:
@@ -110,8 +112,7 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
         if own_pool:
             pool.shutdown()
     objs, recs = [], []
-    for o, r, done in results:
-        main.wait_event(done)  # later work on the caller's stream sees the results
+    for o, r in results:
         objs.extend(o)
         if reconstruct:
             recs.extend(r)
