@@ -990,3 +990,38 @@ def test_rccl_gathers_of_real_cores_single_rank():
         assert all(torch.equal(a, b) for a, b in zip(recs, allv))
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------- degenerate inputs
+def _edge_cases():
+    rng = np.random.default_rng(0)
+    delta = np.zeros((16, 16, 16), np.float32)
+    delta[3, 4, 5] = 2.0
+    return {
+        "zeros": np.zeros((16, 16, 16), np.float32),
+        "const": np.full((16, 16, 16), 3.5, np.float32),
+        "delta": delta,
+        "tiny": (rng.random((16, 16, 16)) * 1e-30).astype(np.float32),
+        "huge": (rng.random((16, 16, 16)) * 1e18).astype(np.float32),
+        "2d": rng.random((12, 20)).astype(np.float32),
+        "1d": rng.random((64,)).astype(np.float32),
+        "prime": rng.random((7, 11, 13)).astype(np.float32),  # a single site: no bond at all
+    }
+
+
+@pytest.mark.parametrize("name", list(_edge_cases()))
+@pytest.mark.parametrize("kw", [{}, {"max_bond": 4}, {"mode": "DCT"}], ids=["exact", "chi4", "dct"])
+def test_degenerate_inputs_match_the_oracle(name, kw):
+    """All-zero, constant, one-voxel, 1e-30 / 1e18 scaled, 1-D, 2-D and single-site inputs: same bonds,
+    same norm and the same reconstruction as the oracle, nothing non-finite."""
+    x = _edge_cases()[name]
+    g = NDMPS.from_tensor(x, **kw)
+    o = OracleNDMPS.from_tensor(x, **kw)
+    rg, ro = g.to_tensor(), o.to_tensor()
+    assert g.bond_sizes() == o.bond_sizes()
+    assert np.isfinite(rg).all()
+    scale = float(np.abs(x).max())
+    assert np.abs(rg - ro).max() <= 2e-6 * scale
+    assert abs(g.norm_value - o.norm_value) <= 2e-6 * o.norm_value
+    if not kw.get("max_bond"):
+        assert np.abs(rg - x).max() <= 2e-6 * scale
