@@ -762,9 +762,12 @@ __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restri
 // each wave multiplies the 32-row slices of its block pairs by the stored 32x32 blocks (f64 MFMA).
 // Nothing but the rotation blocks is read from memory, and only the k wanted columns are formed --
 // the in-loop update streams all np x np of V through the cache hierarchy every step.
-// grid (ceil(k_max / 16), batch); dynamic LDS: np*17 + 4*32*33 doubles.
-__global__ void __launch_bounds__(256)
+// grid (ceil(k_max / 16), batch); NW waves per workgroup (8 while the LDS allows: two waves per SIMD hide
+// each other's LDS / history latency); dynamic LDS: np*17 + NW*32*33 doubles.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
 blk_backacc_kernel(const BatchDesc* __restrict__ desc, Work w, const int* __restrict__ kcols) {
+  constexpr int NT = 64 * NW;
   constexpr int BS = 16, PS = 32, LDJ = PS + 1, LDY = 17;
   const BatchDesc& d = desc[blockIdx.y];
   const int n = d.n, np = w.np, nb = w.nb, half = nb >> 1;
@@ -776,7 +779,7 @@ blk_backacc_kernel(const BatchDesc* __restrict__ desc, Work w, const int* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double (*J)[LDJ] = reinterpret_cast<double (*)[LDJ]>(lds_raw + (int64_t)np * LDY + wave * PS * LDJ);
   const int* invrank = w.invrank + (int64_t)blockIdx.y * np;
-  for (int e = tid; e < np * LDY; e += 256) Y[e] = 0.0;
+  for (int e = tid; e < np * LDY; e += NT) Y[e] = 0.0;
   __syncthreads();
   if (tid < 16 && col0 + tid < k) Y[invrank[col0 + tid] * LDY + tid] = 1.0;
   __syncthreads();
@@ -785,12 +788,12 @@ blk_backacc_kernel(const BatchDesc* __restrict__ desc, Work w, const int* __rest
   const int64_t slot = (int64_t)half * PS * PS;
   const int li = lane & 15, lk = lane >> 4;
   const int steps = d.steps_applied, per_sweep = nb - 1;
-  const int per_wave = (half + 3) / 4;  // block pairs of a step handled by this wave: p = wave + 4 i
+  const int per_wave = (half + NW - 1) / NW;  // block pairs of a step handled by this wave: p = wave + NW i
   // the rotation block of the NEXT (step, pair) item is fetched into registers while the current one
   // is multiplied: the L2 / Infinity-Cache latency of the history reads leaves the critical path
   double2 nx[8];
   auto fetch = [&](int st, int i) {
-    const int p = wave + 4 * i;
+    const int p = wave + NW * i;
     if (st < 0 || p >= half) return;
     const double* src = hist + (int64_t)st * slot + (int64_t)p * PS * PS;
 #pragma unroll
@@ -800,7 +803,7 @@ blk_backacc_kernel(const BatchDesc* __restrict__ desc, Work w, const int* __rest
   for (int st = steps - 1; st >= 0; --st) {
     const int t = st % per_sweep;
     for (int i = 0; i < per_wave; ++i) {
-      const int p = wave + 4 * i;
+      const int p = wave + NW * i;
       if (p < half) {
         int lo, hi;
         pair_blocks(p, t, nb, lo, hi);
@@ -851,7 +854,7 @@ blk_backacc_kernel(const BatchDesc* __restrict__ desc, Work w, const int* __rest
   __syncthreads();
   const int* pos = w.pos + (int64_t)blockIdx.y * np;
   double* Vout = d.V_out;
-  for (int e = tid; e < n * 16; e += 256) {
+  for (int e = tid; e < n * 16; e += NT) {
     const int r = e >> 4, j = e & 15;
     if (col0 + j < k) Vout[(int64_t)r * n + col0 + j] = sgn[j] * Y[pos[r] * LDY + j];
   }
@@ -873,6 +876,7 @@ __global__ void __launch_bounds__(256) blk_gather_kernel(const BatchDesc* __rest
 
 // History mode is used for batches (the throughput path) of matrices that fit the LDS-resident
 // replay (np <= 896 at 16 columns per workgroup) with the 16-wide blocking.
+constexpr int kBackacc8MaxLds = 159 * 1024;  // eight-wave replay while Y and eight J buffers fit
 constexpr int kHistMaxNp = 896;  // np * 17 + 4 * 32 * 33 doubles must fit the 160 KB of LDS
 inline bool use_history(int64_t n_max, int batch) {
   const char* e = getenv("NDMPS_EIG_HISTORY");  // 0 / 1 force it off / on (experiments, tests)
@@ -983,9 +987,12 @@ struct BatchedJacobi {
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_step_kernel<32>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 65 * 8);
       if (attr_err == hipSuccess)
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel<4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (kHistMaxNp * 17 + 4 * 32 * 33) * 8);
+      if (attr_err == hipSuccess)
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel<8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBackacc8MaxLds);
     });
     NDMPS_CHECK_HIP(attr_err);
     const unsigned B = (unsigned)batch;
@@ -1075,9 +1082,13 @@ struct BatchedJacobi {
     }
     NDMPS_CHECK_HIP(hipMemcpyAsync(d_k, k32.data(), sizeof(int) * batch, hipMemcpyHostToDevice, s));
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));  // k32 lives on this stack frame
-    const size_t lds = ((size_t)w.np * 17 + 4 * 32 * 33) * sizeof(double);
-    hipLaunchKernelGGL(blk_backacc_kernel, dim3((unsigned)ndmps::ceil_div(k_max, 16), B), dim3(256), lds, s, desc, w,
-                       d_k);
+    const size_t lds8 = ((size_t)w.np * 17 + 8 * 32 * 33) * sizeof(double);
+    const size_t lds4 = ((size_t)w.np * 17 + 4 * 32 * 33) * sizeof(double);
+    const dim3 grid((unsigned)ndmps::ceil_div(k_max, 16), B);
+    if (lds8 <= (size_t)kBackacc8MaxLds && w.nb / 2 > 4)
+      hipLaunchKernelGGL(blk_backacc_kernel<8>, grid, dim3(512), lds8, s, desc, w, d_k);
+    else
+      hipLaunchKernelGGL(blk_backacc_kernel<4>, grid, dim3(256), lds4, s, desc, w, d_k);
     NDMPS_LAUNCH_CHECK();
     return NDMPS_OK;
   }
