@@ -930,6 +930,39 @@ BlockLayout block_layout(int64_t n_max, int64_t batch) {
 
 // Solver state between the two phases: values() iterates to convergence and delivers the sorted
 // eigenvalues; vectors(k) delivers the first k eigenvectors of every matrix.
+// per host thread: two pinned ints and two events for the pipelined convergence test of values()
+struct HostFlags {
+  int* flags = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int device = -1;
+};
+inline HostFlags* host_flags() {
+  static thread_local HostFlags hf;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (hf.flags != nullptr && hf.device != dev) {  // events belong to a device
+    (void)hipEventDestroy(hf.ev[0]);
+    (void)hipEventDestroy(hf.ev[1]);
+    (void)hipHostFree(hf.flags);
+    hf = HostFlags();
+  }
+  if (hf.flags == nullptr) {
+    int* p = nullptr;
+    if (hipHostMalloc((void**)&p, 64, hipHostMallocPortable) != hipSuccess) return nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+      (void)hipHostFree(p);
+      return nullptr;
+    }
+    hf.flags = p;
+    hf.ev[0] = e0;
+    hf.ev[1] = e1;
+    hf.device = dev;
+  }
+  return &hf;
+}
+
 struct BatchedJacobi {
   int batch = 0;
   int64_t n_max = 0;
@@ -1041,19 +1074,35 @@ struct BatchedJacobi {
       // prepare step 0 of sweep 0 from the initial matrix (diag role only; writes Q[0] / slot 0, D[0])
       step(half, half, 0, 0, 1, 0, 1, 0, 0, 1, -1);
       int g = 0;  // global step counter: G buffer in = g & 1, Q/D parity of the step applied = g & 1
-      while (sweeps < kMaxSweepsBlock) {
-        for (int t = 0; t < steps; ++t, ++g) {
-          const int t_next = (t + 1) % steps;
-          const int sweep_next = sweeps + (t == steps - 1 ? 1 : 0);
-          step(half + n_apply, half, t, t_next, t_next == 0 ? 1 : 0, sweep_next, 0, 0, g & 1, g & 1, g);
+      // The convergence flag of sweep k is read on the host only after sweep k+1 has been enqueued, so
+      // the stream never drains while the host looks at it (the round trip cost ~30 us per sweep, ~75
+      // sweeps per 256^3 volume).  If sweep k turns out to have converged everything, the launches of
+      // sweep k+1 find every matrix marked done by sweep k's check kernel and return at once.
+      HostFlags* hf = host_flags();
+      NDMPS_REQUIRE(hf != nullptr, "pinned flag buffer / events could not be created");
+      int enqueued = 0, verified = 0;
+      while (true) {
+        if (enqueued < kMaxSweepsBlock) {
+          for (int t = 0; t < steps; ++t, ++g) {
+            const int t_next = (t + 1) % steps;
+            const int sweep_next = enqueued + (t == steps - 1 ? 1 : 0);
+            step(half + n_apply, half, t, t_next, t_next == 0 ? 1 : 0, sweep_next, 0, 0, g & 1, g & 1, g);
+          }
+          const int slot = enqueued & 1;
+          hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, enqueued, g & 1, g, flag + slot);
+          NDMPS_LAUNCH_CHECK();
+          NDMPS_CHECK_HIP(hipMemcpyAsync(hf->flags + slot, flag + slot, sizeof(int), hipMemcpyDeviceToHost, s));
+          NDMPS_CHECK_HIP(hipEventRecord(hf->ev[slot], s));
+          ++enqueued;
         }
-        hipLaunchKernelGGL(blk_check_kernel, dim3(1), dim3(64), 0, s, desc, batch, sweeps, g & 1, g, flag);
-        NDMPS_LAUNCH_CHECK();
-        ++sweeps;
-        NDMPS_CHECK_HIP(hipMemcpyAsync(&remaining, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-        NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-        if (remaining == 0) break;
+        if (enqueued > verified + 1 || enqueued == kMaxSweepsBlock) {
+          NDMPS_CHECK_HIP(hipEventSynchronize(hf->ev[verified & 1]));
+          remaining = hf->flags[verified & 1];
+          ++verified;
+          if (remaining == 0 || verified == kMaxSweepsBlock) break;
+        }
       }
+      sweeps = verified;
     }
     if (remaining != 0) {
       ndmps::set_error("block Jacobi did not converge in %d sweeps (n=%lld, %d of %d matrices left)",
