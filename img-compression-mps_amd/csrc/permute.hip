@@ -126,28 +126,50 @@ __global__ void __launch_bounds__(256) encode_tiled_kernel(DevPlan p, const T* _
   T* lds = reinterpret_cast<T*>(smem_raw);
   const int tile = (int)p.tile;
   const uint32_t* __restrict__ tab = p.vec_tab;
-  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const T* s = src + tile_source_base(p, t);
-    if (VEC) {
-      for (int g = threadIdx.x; g < tile / 4; g += 256) {
-        const uint32_t off = tab[3 * g], o01 = tab[3 * g + 1], o23 = tab[3 * g + 2];
-        const Vec4<T> x = *reinterpret_cast<const Vec4<T>*>(s + off);
-        lds[o01 & 0xffffu] = x.v[0];
-        lds[o01 >> 16] = x.v[1];
-        lds[o23 & 0xffffu] = x.v[2];
-        lds[o23 >> 16] = x.v[3];
+  if (VEC) {
+    // Software pipeline over the tiles of this workgroup: the gather of tile k+1 is in flight (in
+    // registers) while tile k is written out, so the gather latency is paid once per workgroup and
+    // not once per tile.  Up to kGroups * 256 groups of 4 elements per tile (tile <= 8192).
+    constexpr int kGroups = 8;
+    const int n_groups = tile / 4;
+    Vec4<T> x[kGroups];
+    auto gather = [&](int64_t t) {
+      const T* s = src + tile_source_base(p, t);
+#pragma unroll
+      for (int u = 0; u < kGroups; ++u) {
+        const int g = threadIdx.x + u * 256;
+        if (g < n_groups) x[u] = *reinterpret_cast<const Vec4<T>*>(s + tab[3 * g]);
       }
-    } else {
-      for (int k = threadIdx.x; k < tile; k += 256) lds[p.order[k]] = s[p.src_sorted[k]];
-    }
-    __syncthreads();
-    T* d = dst + t * tile;
-    if (VEC) {
+    };
+    int64_t t = blockIdx.x;
+    if (t < n_tiles) gather(t);
+    for (; t < n_tiles; t += gridDim.x) {
+#pragma unroll
+      for (int u = 0; u < kGroups; ++u) {
+        const int g = threadIdx.x + u * 256;
+        if (g < n_groups) {
+          const uint32_t o01 = tab[3 * g + 1], o23 = tab[3 * g + 2];
+          lds[o01 & 0xffffu] = x[u].v[0];
+          lds[o01 >> 16] = x[u].v[1];
+          lds[o23 & 0xffffu] = x[u].v[2];
+          lds[o23 >> 16] = x[u].v[3];
+        }
+      }
+      __syncthreads();
+      if (t + gridDim.x < n_tiles) gather(t + gridDim.x);  // flies under the stores below
+      T* d = dst + t * tile;
       for (int k = threadIdx.x * 4; k < tile; k += 1024)
         *reinterpret_cast<Vec4<T>*>(d + k) = *reinterpret_cast<const Vec4<T>*>(lds + k);
-    } else {
-      for (int k = threadIdx.x; k < tile; k += 256) d[k] = lds[k];
+      __syncthreads();
     }
+    return;
+  }
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const T* s = src + tile_source_base(p, t);
+    for (int k = threadIdx.x; k < tile; k += 256) lds[p.order[k]] = s[p.src_sorted[k]];
+    __syncthreads();
+    T* d = dst + t * tile;
+    for (int k = threadIdx.x; k < tile; k += 256) d[k] = lds[k];
     __syncthreads();
   }
 }
