@@ -60,8 +60,6 @@ SIGNATURES = {
     "ndmps_tt_sweep_batched_workspace_bytes": (i64, [C.c_int, C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
                                              C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, i64, vp]),
-    "ndmps_syevj_simple_workspace_bytes": (i64, [i64]),
-    "ndmps_syevj_simple_f64": (C.c_int, [vp, i64, vp, vp, vp, i64, p_int, vp]),
     "ndmps_tt_layout": (C.c_int, [C.c_int, p_i64, i64, p_i64, p_i64, p_i64, p_i64]),
     "ndmps_tt_sweep_f32": (C.c_int, [vp, C.c_int, p_i64, C.c_double, i64, vp, p_i64, p_i64, p_f64,
                                      p_i64, vp, i64, vp]),

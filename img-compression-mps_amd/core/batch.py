@@ -9,7 +9,10 @@ communication is optional and off the critical path: gathering the (small) cores
 reconstructed volumes to every rank with RCCL all_gather (``backend="nccl"`` on ROCm),
 or with gloo on CPU tensors in the tests.
 
-Same function names and argument meaning as the reference where one exists.
+``conv_to_mps`` / ``conv_to_tensors`` / ``compress_list`` / ``benchmark_metric`` / ``run_benchmark``
+keep the reference's names, argument meaning and result layout (they are what a caller of the
+reference switches over); their bodies are this repo's own.  The reference's dataset plumbing
+(``run_full_benchmark``, file discovery, NIfTI loading through nibabel) is out of scope.
 """
 from __future__ import annotations
 
@@ -43,6 +46,7 @@ def _split(n_items: int, groups: int):
 
 
 _group_streams = {}
+_group_pools = {}
 
 
 def group_streams(n: int):
@@ -103,14 +107,13 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
         stream.synchronize()
         return objs, recs
 
-    own_pool = pool is None
-    if own_pool:
-        pool = ThreadPoolExecutor(len(parts))
-    try:
-        results = list(pool.map(work, range(len(parts))))
-    finally:
-        if own_pool:
-            pool.shutdown()
+    if pool is None:
+        # long-lived workers: the solver keeps per-thread pinned flags and events (csrc/eig_block.hip),
+        # a fresh pool per call would allocate them again every time
+        pool = _group_pools.get(len(parts))
+        if pool is None:
+            pool = _group_pools.setdefault(len(parts), ThreadPoolExecutor(len(parts), thread_name_prefix="ndmps-group"))
+    results = list(pool.map(work, range(len(parts))))
     objs, recs = [], []
     for o, r in results:
         objs.extend(o)
@@ -132,105 +135,102 @@ def compress_list(mps_list: Sequence, cutoff: float, max_bond=None) -> None:
         m.compress(cutoff, max_bond=max_bond)
 
 
-def benchmark_metric(mps_list, reference_list=None, metric="compression_ratio", dtype=np.uint16):
-    """benchmark.py:121-146, metric by metric, quirks included: ``ssim`` / ``psnr`` are called as
-    f(reconstruction, original) (so the clip at 0 lands on the original and PSNR's peak is the
-    reconstruction's), and ``gzip_ratio`` quantises the cores in place (``replace=True``)."""
-    from ..utils.metrics import compute_overlap, compute_psnr, compute_ssim_by_dim
+# ------------------------------------------------------------------ quality-vs-ratio sweep
+# Result keys of the reference's metric loop (evaluation/benchmark.py:149-194), in its order.  The keys
+# and the (n_volumes, 1 + n_cutoffs) layout are the data format of the caller side; the evaluation
+# below is this repo's own: one record per (volume, stage), the reconstruction computed once and shared
+# by SSIM and PSNR, everything on the device.
+QUALITY_KEYS = ("ssim", "compression_ratio", "bond_dims", "psnr", "fidelity", "storage", "gzip_bytes",
+                "gzip_ratio")
+_NEEDS_ORIGINAL = {"ssim", "psnr", "shape"}
+_NEEDS_ORIGINAL_MPS = {"fidelity"}
 
-    metric_fn = {
-        "compression_ratio": lambda mps, _: mps.compression_ratio(),
-        "storage": lambda mps, _: mps.get_storage_space(dtype),
-        "gzip_bytes": lambda mps, _: mps.get_bytesize_on_disk(dtype=dtype),
-        "gzip_ratio": lambda mps, _: mps.compression_ratio_on_disk(dtype=dtype, replace=True),
-        "ssim": lambda mps, ref: compute_ssim_by_dim(mps.to_tensor(as_torch=True), ref),
-        "psnr": lambda mps, ref: compute_psnr(mps.to_tensor(as_torch=True), ref),
-        "bond_dims": lambda mps, _: mps.bond_sizes(),
-        "shape": lambda _, ref: tuple(ref.shape),
-        "fidelity": lambda mps, ref: compute_overlap(mps, ref),
-    }
-    if metric not in metric_fn:
+
+def quality_record(obj, original=None, original_mps=None, dtype=np.uint16, keys=QUALITY_KEYS):
+    """All requested figures of one NDMPS at its current truncation, as a dict.
+
+    Conventions inherited from the reference's caller (benchmark.py:125-133), because they change
+    the numbers: SSIM and PSNR take the RECONSTRUCTION as their first argument (the clip at 0 and the
+    PSNR peak therefore refer to it), and ``gzip_ratio`` leaves the cores de-quantised in place
+    (``replace=True``) -- it is evaluated last so the other figures of the stage see the cores as
+    ``compress`` left them."""
+    from ..utils import metrics as M
+
+    rec = None
+    out = {}
+    for key in keys:
+        if key in _NEEDS_ORIGINAL and original is None:
+            raise ValueError(f"metric {key!r} needs the original tensor")
+        if key in _NEEDS_ORIGINAL_MPS and original_mps is None:
+            raise ValueError(f"metric {key!r} needs the untruncated NDMPS")
+        if key in ("ssim", "psnr") and rec is None:
+            rec = obj.to_tensor(as_torch=True)
+    for key in sorted(keys, key=lambda k: k == "gzip_ratio"):  # stable: gzip_ratio moves to the end
+        if key == "ssim":
+            out[key] = M.compute_ssim_by_dim(rec, original)
+        elif key == "psnr":
+            out[key] = M.compute_psnr(rec, original)
+        elif key == "fidelity":
+            out[key] = M.compute_overlap(obj, original_mps)
+        elif key == "compression_ratio":
+            out[key] = obj.compression_ratio()
+        elif key == "bond_dims":
+            out[key] = obj.bond_sizes()
+        elif key == "storage":
+            out[key] = obj.get_storage_space(dtype)
+        elif key == "gzip_bytes":
+            out[key] = obj.get_bytesize_on_disk(dtype=dtype)
+        elif key == "gzip_ratio":
+            out[key] = obj.compression_ratio_on_disk(dtype=dtype, replace=True)
+        elif key == "shape":
+            out[key] = tuple(original.shape)
+        else:
+            raise ValueError(f"Unsupported metric: {key}")
+    return out
+
+
+def benchmark_metric(mps_list, reference_list=None, metric="compression_ratio", dtype=np.uint16):
+    """One figure for every NDMPS of the list (caller-side counterpart of benchmark.py:121-146).
+    ``reference_list`` holds the originals (ssim / psnr / shape) or the untruncated NDMPS (fidelity)."""
+    if metric not in QUALITY_KEYS + ("shape",):
         raise ValueError(f"Unsupported metric: {metric}")
     if reference_list and len(reference_list) != len(mps_list):
         raise IndexError("Length mismatch: reference_list and mps_list must have the same length.")
-    results = []
-    for i, mps in enumerate(mps_list):
-        ref = reference_list[i] if reference_list else None
-        results.append(metric_fn[metric](mps, ref))
-    return results
+    refs = reference_list if reference_list else [None] * len(mps_list)
+    as_mps = metric in _NEEDS_ORIGINAL_MPS
+    return [quality_record(m, None if as_mps else r, r if as_mps else None, dtype, (metric,))[metric]
+            for m, r in zip(mps_list, refs)]
 
 
-def run_benchmark(mps_list, original_tensors_list, cutoff_list, verbose=True):
-    """benchmark.py:149-194: all metrics before compression and after every (cumulative) cutoff;
-    same result keys, order and array layout ((n_files, 1 + n_cutoffs), ``bond_dims`` left as lists)."""
+def run_benchmark(mps_list, original_tensors_list, cutoff_list, verbose=True, dtype=np.uint16):
+    """Quality figures before truncation and after every cutoff of ``cutoff_list`` (applied
+    cumulatively, in place), as ``{key: array (n_volumes, 1 + n_cutoffs)}`` with ``bond_dims`` kept as
+    nested lists [stage][volume] -- the layout of benchmark.py:149-194."""
     from copy import deepcopy
 
-    original_mps_list = deepcopy(mps_list)
-    metrics = [
-        ("ssim", original_tensors_list),
-        ("compression_ratio", None),
-        ("bond_dims", None),
-        ("psnr", original_tensors_list),
-        ("fidelity", original_mps_list),
-        ("storage", None),
-        ("gzip_bytes", None),
-        ("gzip_ratio", None),
-    ]
-    results = {name: [] for name, _ in metrics}
-    for name, ref in metrics:
-        results[name].append(benchmark_metric(mps_list, ref, metric=name))
-    for i, cutoff in enumerate(cutoff_list):
+    untouched = deepcopy(list(mps_list))
+    stages = []
+
+    def take_stage():
+        stages.append([quality_record(m, x, m0, dtype)
+                       for m, x, m0 in zip(mps_list, original_tensors_list, untouched)])
+
+    take_stage()
+    for n, cutoff in enumerate(cutoff_list, 1):
         if verbose:
-            print(f"Status: {100 * (i + 1) / len(cutoff_list):.2f}% - Cutoff: {cutoff}")
+            print(f"Status: {100 * n / len(cutoff_list):.2f}% - Cutoff: {cutoff}")
         compress_list(mps_list, cutoff)
-        for name, ref in metrics:
-            results[name].append(benchmark_metric(mps_list, ref, metric=name))
-    for key in results:
-        if not results[key] or not results[key][0]:
+        take_stage()
+    results = {}
+    for key in QUALITY_KEYS:
+        table = [[rec[key] for rec in stage] for stage in stages]
+        if not table[0]:
             results[key] = []
-        elif key != "bond_dims" and isinstance(results[key][0], (list, np.ndarray)) and np.ndim(results[key][0]) > 0:
-            results[key] = np.array(results[key]).T
+        elif key == "bond_dims":
+            results[key] = table
+        else:
+            results[key] = np.array(table).T
     return results
-
-
-def run_full_benchmark(dataset_path, cutoff_list, result_file, datatype="MRI", mode="DCT", start=0, end=-1,
-                       ending=".gz", shape=None):
-    """benchmark.py:197-242: load every file of a dataset directory, encode, run the cutoff sweep and
-    write the result JSON (same keys, same order; relative result paths land under
-    ``src/evaluation/results`` like the reference's).  Returns the result dictionary."""
-    import json
-    from pathlib import Path
-
-    from ..utils.loaders import find_specific_files, get_shapes, load_tensors, mri_to_slices
-
-    dataset_path = Path(dataset_path)
-    result_path = Path(result_file)
-    if not result_path.is_absolute() and not str(result_path).startswith("src/evaluation/results"):
-        result_path = Path("src/evaluation/results") / result_path
-    files = find_specific_files(dataset_path, ending)
-    files = files[start:] if end == -1 else files[start:end]
-    if not files:
-        raise FileNotFoundError(f"No files with extension {ending} found in {dataset_path}")
-    data_list, bitsize_list = load_tensors(files, ending, shape)
-    if datatype == "MRI_Slice":
-        data_list, bitsize_list = mri_to_slices(data_list, bitsize_list)
-    mps_list = conv_to_mps(data_list, mode)
-    print("Starting benchmark...")
-    metrics = run_benchmark(mps_list, data_list, cutoff_list)
-    print(f"Saving results to {result_path}")
-    result_dict = {
-        "datatype": datatype,
-        "mode": mode,
-        "files": files,
-        "cutoff_list": cutoff_list.tolist(),
-        "bitsize_list": bitsize_list,
-        "shapes": get_shapes(data_list),
-        **{k: v.tolist() if hasattr(v, "tolist") else v for k, v in metrics.items()},
-    }
-    result_path.parent.mkdir(parents=True, exist_ok=True)
-    with open(result_path, "w") as f:
-        json.dump(result_dict, f, indent=2)
-    return result_dict
 
 
 # ------------------------------------------------------------------------ collectives

@@ -93,6 +93,51 @@ def _header(data: bytes):
     return header, 16 + hlen
 
 
+def _gunzip_exactly(member: bytes, want: int, index: int) -> bytes:
+    """Inflate one gzip member that must hold exactly ``want`` bytes; never inflates more than that
+    (+1 to notice an oversized member), so a crafted container cannot balloon in memory."""
+    import zlib
+
+    inflater = zlib.decompressobj(16 + zlib.MAX_WBITS)
+    try:
+        raw = inflater.decompress(member, want + 1)
+    except zlib.error as exc:
+        raise ValueError(f"core {index}: corrupt gzip member ({exc})") from None
+    if len(raw) != want or inflater.unconsumed_tail or not inflater.eof:
+        raise ValueError(f"core {index}: gzip member does not hold exactly {want} bytes")
+    return raw
+
+
+def _checked_layout(header):
+    """(shape, dtype name, bonds, site dims) of a container header, or ValueError: everything the
+    device side will size buffers from is validated here, on the host, before any allocation."""
+    try:
+        shape = tuple(header["shape"])
+        name = header["dtype"]
+        bonds, dims = list(header["bonds"]), list(header["qubit_size"])
+        members = list(header["member_bytes"])
+    except (KeyError, TypeError):
+        raise ValueError("inconsistent NDMPS container header") from None
+    if name not in _DTYPES:
+        raise ValueError(f"unsupported core dtype {name!r}")
+    if len(bonds) != len(dims) + 1 or len(members) != len(dims) or not dims:
+        raise ValueError("inconsistent NDMPS container header")
+    ints = [*shape, *bonds, *dims, *members]
+    if any(not isinstance(v, int) or isinstance(v, bool) or v < 1 for v in ints):
+        raise ValueError("NDMPS container header: shape, site dimensions, bonds and sizes must be positive integers")
+    numel = 1
+    for d in dims:
+        numel *= d
+    if bonds[0] != 1 or bonds[-1] != 1:
+        raise ValueError("NDMPS container header: open boundary bonds must be 1")
+    left = 1
+    for i, d in enumerate(dims[:-1]):
+        left *= d
+        if bonds[i + 1] > min(left, numel // left):
+            raise ValueError(f"NDMPS container header: bond {i + 1} = {bonds[i + 1]} exceeds the rank of its unfolding")
+    return shape, name, bonds, dims
+
+
 def loads(data: bytes, device=None):
     """Rebuild the NDMPS on ``device`` (default: the current HIP device).  Quantised cores are
     scaled back exactly like ``compress_to_dtype(replace=True)`` leaves them (filetools.py:29-39)."""
@@ -103,15 +148,9 @@ def loads(data: bytes, device=None):
     from .ndmps import NDMPS, _plan_for
 
     header, off = _header(data)
+    shape, name, bonds, dims = _checked_layout(header)
     _lib.require_device()
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    shape = tuple(header["shape"])
-    name = header["dtype"]
-    if name not in _DTYPES:
-        raise ValueError(f"unsupported core dtype {name!r}")
-    bonds, dims = header["bonds"], header["qubit_size"]
-    if len(bonds) != len(dims) + 1 or len(header["member_bytes"]) != len(dims):
-        raise ValueError("inconsistent NDMPS container header")
     with torch.cuda.device(device):
         plan = _plan_for(shape, device.index or 0)
         if [int(q) for q in plan.qubit_size] != [int(d) for d in dims]:
@@ -120,12 +159,10 @@ def loads(data: bytes, device=None):
         for i, nbytes in enumerate(header["member_bytes"]):
             if off + nbytes > len(data):
                 raise ValueError("truncated NDMPS container (payload)")
-            raw = gzip.decompress(data[off:off + nbytes])
-            off += nbytes
             cshape = (bonds[i], dims[i], bonds[i + 1])
             want = int(np.prod(cshape)) * np.dtype(_DTYPES[name]).itemsize
-            if len(raw) != want:
-                raise ValueError(f"core {i}: {len(raw)} bytes, expected {want}")
+            raw = _gunzip_exactly(data[off:off + nbytes], want, i)
+            off += nbytes
             arr = np.frombuffer(raw, dtype=_DTYPES[name]).reshape(cshape)
             if name == "float32":
                 cores.append(torch.from_numpy(arr.copy()).to(device))

@@ -150,7 +150,9 @@ class NDMPS:
         self.norm_value = norm_value
         self.mode = mode
         self.boundary_list = np.array(boundary_list)
-        self._shape = None
+        # tensor shape: known from the map when one is handed in (the reference's constructor allows
+        # that, ndmps.py:17-35), set by from_tensors / codec.loads otherwise
+        self._shape = tuple(int(v) for v in np.shape(encoding_map)[:-1]) if encoding_map is not None else None
 
     # The reference keeps the (*shape, L) int64 map; here it is built on first access only.
     @property
@@ -163,6 +165,8 @@ class NDMPS:
     @encoding_map.setter
     def encoding_map(self, value):
         self._encoding_map = value
+        if value is not None:
+            self._shape = tuple(int(v) for v in np.shape(value)[:-1])
 
     # ---------------------------------------------------------------------- encode
     @classmethod
@@ -207,7 +211,11 @@ class NDMPS:
                 if tensor.dim() == 0:
                     raise ValueError("Shape cannot be empty.")
                 # bf16 / fp16 volumes stay 2 bytes per voxel in HBM until here; arithmetic is fp32
-                x = tensor.detach().to(device=device, dtype=torch.float32, copy=True).contiguous()
+                # the volume is only written to when it is normalised in place: copy then, otherwise
+                # an fp32 volume already resident on the device is read where it lies
+                x = tensor.detach().to(device=device, dtype=torch.float32).contiguous()
+                if norm and x.data_ptr() == tensor.data_ptr():
+                    x = x.clone()
             else:
                 arr = np.asarray(tensor)
                 if arr.ndim == 0:

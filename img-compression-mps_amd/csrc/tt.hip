@@ -459,6 +459,21 @@ extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int6
                                         int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(L >= 1 && h_dims && h_bonds && h_cores && d_dense, "bad chain argument");
   NDMPS_REQUIRE(h_bonds[0] == 1 && h_bonds[L] == 1, "open boundary bonds must be 1");
+  {
+    // the intermediates ping-pong between d_ws and d_dense (N = prod(dims) elements): every bond must be
+    // at most the product of the site dims on either side of it, as any MPS of a dense tensor has
+    int64_t numel = 1, left = 1;
+    for (int i = 0; i < L; ++i) {
+      NDMPS_REQUIRE(h_dims[i] >= 1 && h_cores[i], "dims[%d] must be positive and core %d non-NULL", i, i);
+      numel *= h_dims[i];
+    }
+    for (int i = 0; i < L; ++i) {
+      left *= h_dims[i];
+      NDMPS_REQUIRE(h_bonds[i + 1] >= 1 && h_bonds[i + 1] <= left && h_bonds[i + 1] <= numel / left,
+                    "bond %d = %lld exceeds min(%lld, %lld), the rank any unfolding can have", i + 1,
+                    (long long)h_bonds[i + 1], (long long)left, (long long)(numel / left));
+    }
+  }
   const int64_t need = ndmps_chain_workspace_bytes(L, h_dims, h_bonds);
   if (!d_ws || ws_bytes < need) {
     ndmps::set_error("chain workspace too small: %lld < %lld", (long long)ws_bytes, (long long)need);

@@ -1,16 +1,15 @@
-"""Volume loaders and dataset helpers of the benchmark driver, host side.
+"""Volume file readers, host side.
 
-Mirrors ``load_tensors`` (src/imgcompressionmps/evaluation/benchmark.py:16-55) and the helpers it
-is used with (utils/filetools.py:42-68 ``mri_to_slices``, :83-92 ``find_specific_files``,
-:119-123 ``get_shapes``).  The reference reads ``.nii.gz`` through nibabel, which is not available
-here; ``read_nifti`` is a self-contained NIfTI-1 single-file reader written from the format
+The reference reads ``.nii.gz`` through nibabel and ``.npz`` through NumPy
+(src/imgcompressionmps/evaluation/benchmark.py:40-48); nibabel is not available here and the
+reference's dataset plumbing around it (file discovery, slicing, cropping) is out of scope.
+``read_nifti`` is a self-contained NIfTI-1 single-file reader written from the format
 definition (348-byte header, column-major voxel data at ``vox_offset``, ``scl_slope`` / ``scl_inter``
 scaling) that returns what ``nib.load(p).get_fdata()`` / ``.header.get_data_dtype()`` return: the
 scaled float64 array and the on-disk dtype.  Parity with nibabel itself is unpinned (no nibabel, no
 NIfTI fixture in the reference); tests check the reader against files written field by field.
 """
 import gzip
-import os
 import struct
 
 import numpy as np
@@ -57,50 +56,17 @@ def read_nifti(path):
     return data, dtype
 
 
-def load_tensors(files, ending, shape=None):
-    """benchmark.py:16-55: list of arrays and of the bit sizes of their on-disk dtypes; ``shape`` =
-    (B, H, W) crops the leading three axes."""
-    if not (ending.endswith(".gz") or ending.endswith(".npz")):
-        raise ValueError(f"Unsupported file extension: {ending}")
-    B, H, W = shape if shape else (None, None, None)
-    data_list, bitsize_list = [], []
-    for i, path in enumerate(files):
-        print(f"Loading file {i + 1}/{len(files)}")
-        if ending.endswith(".gz"):
-            data, dtype = read_nifti(path)
-        else:
-            with np.load(path) as archive:  # allow_pickle stays False
-                data = archive["sequence"]
-                dtype = data.dtype
-        if shape:
-            data = data[:B, :H, :W]
-        data_list.append(data)
-        bitsize_list.append(get_num_bits(dtype))
-    return data_list, bitsize_list
-
-
-def mri_to_slices(data_list, bitsize_list=None):
-    """filetools.py:42-68: the three central 2-D slices of every 3-D volume (non-3-D entries are skipped)."""
-    slices, bits = [], []
-    for i, volume in enumerate(data_list):
-        if volume.ndim != 3:
-            print(f"Skipping non-3D volume at index {i} with shape {volume.shape}")
-            continue
-        slices.extend([volume[volume.shape[0] // 2, :, :], volume[:, volume.shape[1] // 2, :],
-                       volume[:, :, volume.shape[2] // 2]])
-        bits.extend([bitsize_list[i] if bitsize_list else 16] * 3)
-    return slices, bits
-
-
-def find_specific_files(directory_path, file_extension=None):
-    """filetools.py:83-92: recursive listing in os.walk order, optionally filtered by suffix."""
-    files = []
-    for root, _, filenames in os.walk(directory_path):
-        for filename in filenames:
-            if file_extension is None or filename.endswith(file_extension):
-                files.append(os.path.join(root, filename))
-    return files
-
-
-def get_shapes(data_list):
-    return [np.shape(data) for data in data_list]
+def load_volume(path):
+    """(array, bits of the on-disk dtype) of one volume file: ``.nii`` / ``.nii.gz`` through
+    ``read_nifti``, ``.npz`` through its ``"sequence"`` entry (the two containers the reference's
+    datasets come in, evaluation/benchmark.py:40-48)."""
+    name = str(path)
+    if name.endswith((".nii", ".nii.gz")):
+        data, dtype = read_nifti(path)
+    elif name.endswith(".npz"):
+        with np.load(path) as archive:  # allow_pickle stays False
+            data = archive["sequence"]
+        dtype = data.dtype
+    else:
+        raise ValueError(f"unsupported volume file: {name}")
+    return data, get_num_bits(dtype)

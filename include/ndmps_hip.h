@@ -157,11 +157,6 @@ int ndmps_syevj_batched_vectors_f64(int batch, double* d_G, int64_t stride_G, co
                                     double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
                                     const int64_t* h_k, void* d_ws, int64_t ws_bytes,
                                     ndmps_stream_t stream);
-/* same contract, scalar-parallel Jacobi (one launch per rotation step); kept as the
- * cross-check of the block solver above */
-int64_t ndmps_syevj_simple_workspace_bytes(int64_t n);
-int ndmps_syevj_simple_f64(double* d_G, int64_t n, double* d_V, double* d_w, void* d_ws,
-                           int64_t ws_bytes, int* h_sweeps, ndmps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * MPS sweep: replaces quimb MatrixProductState.from_dense (core/ndmps.py:74).

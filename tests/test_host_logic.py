@@ -160,7 +160,6 @@ def test_workspace_queries_and_argument_checks_need_no_gpu():
     assert lib.ndmps_gram_workspace_bytes(32768, 512) > 0
     assert lib.ndmps_syevj_workspace_bytes(512) >= 2 * 512 * 512 * 8  # G and V, in place
     assert lib.ndmps_syevj_workspace_bytes(7) >= 2 * 32 * 32 * 8  # padded to one 32-wide block pair
-    assert lib.ndmps_syevj_simple_workspace_bytes(7) >= 4 * 8 * 8 * 8  # odd sizes padded to even
     assert lib.ndmps_compress_bond_workspace_bytes(64, 8, 64, 8, 64) > 0
     assert lib.ndmps_reduce_workspace_bytes() > 0
     # argument validation happens before any HIP call

@@ -72,34 +72,19 @@ def test_read_nifti_rejects_garbage(tmp_path):
         loaders.read_nifti(p)
 
 
-def test_load_tensors_conventions(tmp_path, capsys):
-    """benchmark.py:16-55: ending filter, 'sequence' key, (B, H, W) crop, bit sizes of the on-disk dtype."""
+def test_load_volume_containers(tmp_path):
+    """The two containers of the reference's datasets (benchmark.py:40-48): 'sequence' entry of an .npz,
+    NIfTI through read_nifti; bit size of the on-disk dtype."""
     seq = np.arange(4 * 5 * 6, dtype=np.uint8).reshape(4, 5, 6)
     np.savez(tmp_path / "a.npz", sequence=seq)
     vol = np.arange(3 * 4 * 5, dtype=np.int16).reshape(3, 4, 5)
     _write_nifti(tmp_path / "b.nii.gz", vol, 4)
-    data, bits = loaders.load_tensors([str(tmp_path / "a.npz")], ".npz", shape=(2, 3, 4))
-    assert bits == [8] and np.array_equal(data[0], seq[:2, :3, :4])
-    data, bits = loaders.load_tensors([str(tmp_path / "b.nii.gz")], ".gz")
-    assert bits == [16] and data[0].dtype == np.float64 and np.array_equal(data[0], vol)
-    assert "Loading file 1/1" in capsys.readouterr().out
+    data, bits = loaders.load_volume(tmp_path / "a.npz")
+    assert bits == 8 and np.array_equal(data, seq)
+    data, bits = loaders.load_volume(str(tmp_path / "b.nii.gz"))
+    assert bits == 16 and data.dtype == np.float64 and np.array_equal(data, vol)
     with pytest.raises(ValueError):
-        loaders.load_tensors([], ".nii")
-    assert loaders.get_shapes(data) == [(3, 4, 5)]
-
-
-def test_mri_to_slices_and_find_files(tmp_path, capsys):
-    v = np.arange(4 * 6 * 8).reshape(4, 6, 8)
-    slices, bits = loaders.mri_to_slices([v, np.zeros((3, 3))], [12, 8])
-    assert "Skipping non-3D volume at index 1" in capsys.readouterr().out
-    assert bits == [12, 12, 12]
-    assert np.array_equal(slices[0], v[2]) and np.array_equal(slices[1], v[:, 3]) and np.array_equal(slices[2], v[:, :, 4])
-    assert loaders.mri_to_slices([v])[1] == [16, 16, 16]
-    (tmp_path / "sub").mkdir()
-    (tmp_path / "sub" / "x.nii.gz").write_bytes(b"")
-    (tmp_path / "y.npz").write_bytes(b"")
-    assert sorted(loaders.find_specific_files(tmp_path, ".gz")) == [str(tmp_path / "sub" / "x.nii.gz")]
-    assert len(loaders.find_specific_files(tmp_path)) == 2
+        loaders.load_volume(tmp_path / "c.txt")
 
 
 def test_container_framing_errors():
@@ -111,3 +96,53 @@ def test_container_framing_errors():
     truncated = codec.MAGIC + struct.pack("<II", codec.VERSION, 500) + b"{}"
     with pytest.raises(ValueError):
         codec.loads(truncated)
+
+
+def _container(header: dict, payload: bytes = b"") -> bytes:
+    import json
+
+    hb = json.dumps(header).encode()
+    return codec.MAGIC + struct.pack("<II", codec.VERSION, len(hb)) + hb + payload
+
+
+def test_container_header_is_validated_on_the_host():
+    """A crafted header must not reach the device: bonds larger than the rank of their unfolding would make
+    the chain contraction write past its N-element buffers (dims [2,2,2] with bonds [1,8,8,1])."""
+    good = {"version": 1, "shape": [2, 2, 2], "mode": "Std", "norm": False, "norm_value": 1.0, "dim": 3,
+            "qubit_size": [2, 2, 2], "bonds": [1, 2, 2, 1], "dtype": "float32", "bounds": [[0, 0]] * 3,
+            "member_bytes": [1, 1, 1]}
+    for patch in ({"bonds": [1, 8, 8, 1]}, {"bonds": [2, 2, 2, 1]}, {"bonds": [1, 2, 2]}, {"bonds": [1, 0, 2, 1]},
+                  {"bonds": [1, 2.5, 2, 1]}, {"qubit_size": [2, -2, 2]}, {"member_bytes": [1, 1]},
+                  {"dtype": "int32"}, {"shape": "abc"}):
+        with pytest.raises(ValueError):
+            codec.loads(_container({**good, **patch}))
+    bad = dict(good)
+    del bad["bonds"]
+    with pytest.raises(ValueError):
+        codec.loads(_container(bad))
+
+
+def test_gzip_members_are_inflated_with_a_length_cap():
+    bomb = gzip.compress(b"\0" * (1 << 24))  # 16 MiB of zeros in ~16 KB
+    with pytest.raises(ValueError):
+        codec._gunzip_exactly(bomb, 64, 0)
+    with pytest.raises(ValueError):
+        codec._gunzip_exactly(gzip.compress(b"abc"), 64, 0)
+    with pytest.raises(ValueError):
+        codec._gunzip_exactly(b"not gzip", 8, 0)
+    assert codec._gunzip_exactly(gzip.compress(b"12345678"), 8, 0) == b"12345678"
+
+
+def test_chain_contraction_rejects_bonds_no_unfolding_can_have():
+    """ndmps_chain_contract_f32 ping-pongs its intermediates through an N-element buffer; the argument check
+    runs before any HIP call, so it can be exercised without a GPU."""
+    import ctypes as C
+
+    from imgcompressionmps_amd import _lib
+
+    lib = _lib.load()
+    dims, fake = _lib.i64_array([2, 2, 2]), (C.c_void_p * 3)(64, 64, 64)
+    for bonds in ([1, 8, 8, 1], [1, 2, 8, 1], [1, 0, 2, 1], [2, 2, 2, 1]):
+        rc = lib.ndmps_chain_contract_f32(3, dims, _lib.i64_array(bonds), fake, C.c_void_p(64), C.c_void_p(64),
+                                          1 << 20, None)
+        assert rc == _lib.EINVAL, bonds
