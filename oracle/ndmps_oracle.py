@@ -75,13 +75,14 @@ class OracleNDMPS:
             flat_dest = _im.flat_destination(shape).reshape(-1)
             dense.reshape(-1)[flat_dest] = tensor.reshape(-1)
 
-        cores, _ = mps_from_dense(dense, qubit_size, cutoff=cutoff, max_bond=max_bond)
+        cores, spectra = mps_from_dense(dense, qubit_size, cutoff=cutoff, max_bond=max_bond)
         mps = OracleMPS(cores)
         boundary = [[np.min(a), np.max(a)] for a in mps.arrays]
         norm_value = np.sqrt(mps @ mps)
         obj = cls(mps, qubit_size, enc, boundary, norm, norm_value, mode, tensor.ndim)
         obj._flat_dest = flat_dest
         obj._shape = shape
+        obj.sweep_spectra = spectra  # singular values per bond (diagnostic the GPU path also keeps)
         return obj
 
     # ------------------------------------------------------------- bookkeeping
