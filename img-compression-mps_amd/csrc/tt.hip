@@ -112,6 +112,20 @@ int64_t kept_rank(const std::vector<double>& sigma, double cutoff, int64_t max_b
   return std::min(k, n);
 }
 
+// The bond-capped sweep wants chi <= 128 of the n eigenpairs of every site: the direct solver
+// (eig_tridiag.hip).  Exact sweeps (all eigenpairs above the cutoff) and orders beyond its limit stay on
+// the block Jacobi.
+inline bool use_topk(int64_t n_max, int64_t max_bond) {
+  if (getenv("NDMPS_SWEEP_JACOBI")) return false;  // A/B timing
+  return max_bond > 0 && max_bond <= ndmps_syevd_topk_max_k() && n_max <= ndmps_syevd_topk_max_n();
+}
+inline int64_t eig_workspace_bytes(int64_t n_max, int batch, int64_t max_bond) {
+  const int64_t jac = ndmps_syevj_batched_workspace_bytes(n_max, batch);
+  if (max_bond > 0 && max_bond <= ndmps_syevd_topk_max_k() && n_max <= ndmps_syevd_topk_max_n())
+    return std::max(jac, ndmps_syevd_topk_workspace_bytes(n_max, batch, std::min(max_bond, n_max)));
+  return jac;
+}
+
 // upper bound of ndmps_gram_workspace_bytes(m, n') over every n' <= n (the actual bond may
 // come out smaller than the worst case the layout is sized for): slabs * tiles <=
 // max(1024, tiles(n)), 64 x 64 doubles each.
@@ -174,7 +188,7 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
   used = arena_bytes(used, 8, (int64_t)batch * sq);                     // V / U
   used = arena_bytes(used, 8, (int64_t)batch * out.small_max);          // w
   used = arena_bytes(used, 8, (int64_t)batch * out.small_max);          // sigma
-  used = arena_bytes(used, 1, ndmps_syevj_batched_workspace_bytes(out.small_max, batch));
+  used = arena_bytes(used, 1, eig_workspace_bytes(out.small_max, batch, max_bond));
   used = arena_bytes(used, 1, out.gram_ws);                             // shared, stream-ordered
   used = arena_bytes(used, 8, (int64_t)batch * out.wide_elems);         // A64 per volume
   used = arena_bytes(used, 8, out.wide_elems);                          // U_k^T A64, shared
@@ -231,7 +245,7 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
   double* V = ar.take<double>((int64_t)batch * sq);
   double* w = ar.take<double>((int64_t)batch * lay.small_max);
   double* sig = ar.take<double>((int64_t)batch * lay.small_max);
-  const int64_t ev_ws_bytes = ndmps_syevj_batched_workspace_bytes(lay.small_max, batch);
+  const int64_t ev_ws_bytes = eig_workspace_bytes(lay.small_max, batch, max_bond);
   char* ev_ws = ar.take<char>(ev_ws_bytes);
   char* gram_ws = ar.take<char>(lay.gram_ws);
   double* A64 = ar.take<double>((int64_t)batch * lay.wide_elems);
@@ -248,6 +262,7 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
   }
   const int64_t spec_total = h_spec_offsets ? h_spec_offsets[L] : 0;
   std::vector<double> host_w((size_t)batch * lay.small_max);
+  std::vector<int> eig_status;
 
   for (int i = L - 1; i >= 1; --i) {
     // ---- small-side Gram matrices
@@ -271,8 +286,16 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
     }
     // ---- one batched eigen-solve for the site
     int sweeps = 0;
-    NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(),
-                                             ev_ws, ev_ws_bytes, &sweeps, s));
+    int64_t site_n = 0;
+    for (int b = 0; b < batch; ++b) site_n = std::max(site_n, eig_n[b]);
+    const bool topk = use_topk(site_n, max_bond);
+    const int64_t k_cap = std::min<int64_t>(max_bond, site_n);
+    if (topk)
+      NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
+                                            ev_ws_bytes, s));
+    else
+      NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(),
+                                               ev_ws, ev_ws_bytes, &sweeps, s));
     NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
                                    hipMemcpyDeviceToHost, s));
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));
@@ -286,8 +309,19 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
       if (h_spectra && h_spec_offsets)
         memcpy(h_spectra + (int64_t)b * spec_total + h_spec_offsets[i], sv.data(), small * sizeof(double));
     }
-    NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(),
-                                              ev_ws, ev_ws_bytes, s));
+    if (topk) {
+      eig_status.assign(batch, 0);
+      NDMPS_TRY(ndmps_syevd_topk_vectors_f64(batch, eig_n.data(), kept.data(), k_cap, ev_ws, ev_ws_bytes,
+                                             eig_status.data(), s));
+      for (int b = 0; b < batch; ++b)
+        if (eig_status[b] != 0) {
+          ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", i, b);
+          return NDMPS_ENOCONV;
+        }
+    } else {
+      NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(),
+                                                ev_ws, ev_ws_bytes, s));
+    }
     // ---- core and carried matrix per volume
     for (int b = 0; b < batch; ++b) {
       const int64_t n = h_dims[i] * chi_r[b];

@@ -158,6 +158,22 @@ int ndmps_syevj_batched_vectors_f64(int batch, double* d_G, int64_t stride_G, co
                                     const int64_t* h_k, void* d_ws, int64_t ws_bytes,
                                     ndmps_stream_t stream);
 
+/* Leading k eigenpairs by a direct method (Householder tridiagonalisation, multi-section on the Sturm
+ * sequence, inverse iteration with a Cholesky-QR of the block, reflectors replayed on the k columns): the
+ * path of the bond-capped sweep, where k = chi <= 128 of n = d chi <= 4096 are wanted (replaces the thin SVD
+ * quimb's from_dense calls per site, core/ndmps.py:74).  Same conventions as ndmps_syevj_*: w descending,
+ * eigenvector c in column c of V (ld n), largest-magnitude component positive.  Two phases like the Jacobi
+ * pair above; both are asynchronous on `stream` (vectors synchronises only when h_status is given;
+ * h_status[b] != 0: the orthonormalisation of matrix b broke down). */
+int64_t ndmps_syevd_topk_max_n(void);
+int64_t ndmps_syevd_topk_max_k(void);
+int64_t ndmps_syevd_topk_workspace_bytes(int64_t n_max, int batch, int64_t k_max);
+int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t stride_G, const int64_t* h_n,
+                                double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
+                                int64_t k_max, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const int64_t* h_k, int64_t k_max,
+                                 void* d_ws, int64_t ws_bytes, int* h_status, ndmps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * MPS sweep: replaces quimb MatrixProductState.from_dense (core/ndmps.py:74).
  * Right->left, per site: unfold (prod_{j<i} d_j) x (d_i chi_{i+1}) -> SVD (Gram + Jacobi,

@@ -598,6 +598,117 @@ def test_batched_eigensolver_large_and_two_phase(sizes):
         assert np.array_equal(v, full[b][:, :k])
 
 
+# ---------------------------------------------------------------- direct top-k solver (eig_tridiag.hip)
+def _topk(lib, mats, ks, k_max=None):
+    """ndmps_syevd_topk_* on a batch of symmetric matrices: (eigenvalues, leading k eigenvectors) per matrix."""
+    sizes = [m.shape[0] for m in mats]
+    nmax, B = max(sizes), len(mats)
+    k_max = k_max or max(ks)
+    g_all = np.zeros((B, nmax * nmax))
+    for b, m in enumerate(mats):
+        g_all[b, : m.size] = m.reshape(-1)
+    tg = dev(g_all)
+    tv = torch.zeros_like(tg)
+    tw = torch.zeros((B, nmax), dtype=torch.float64, device=DEV)
+    nbytes = lib.ndmps_syevd_topk_workspace_bytes(nmax, B, k_max)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    n_arr = _lib.i64_array(sizes)
+    _lib.check(lib.ndmps_syevd_topk_values_f64(B, tg.data_ptr(), nmax * nmax, n_arr, tv.data_ptr(), nmax * nmax,
+                                               tw.data_ptr(), nmax, k_max, ws.data_ptr(), nbytes, sp()))
+    status = (C.c_int * B)()
+    _lib.check(lib.ndmps_syevd_topk_vectors_f64(B, n_arr, _lib.i64_array(ks), k_max, ws.data_ptr(), nbytes, status, sp()))
+    assert list(status) == [0] * B
+    out = []
+    for b, (n, k) in enumerate(zip(sizes, ks)):
+        out.append((tw[b, :n].cpu().numpy(), tv[b, : n * n].cpu().numpy().reshape(n, n)[:, :k]))
+    return out
+
+
+def _check_topk(g, w, v, k, tol_scale=1.0):
+    n = g.shape[0]
+    ref = np.linalg.eigvalsh(g)[::-1]
+    scale = max(abs(ref[0]), abs(ref[-1]), 1e-300)
+    eps = 2e-15 * max(n, 50) * tol_scale
+    assert np.all(np.diff(w) <= 1e-15 * scale)
+    assert np.abs(w - ref).max() <= eps * scale
+    assert np.abs(v.T @ v - np.eye(k)).max() <= eps
+    assert np.abs(g @ v - v * w[None, :k]).max() <= eps * scale
+    for j in range(k):  # sign convention: largest component positive
+        assert v[np.argmax(np.abs(v[:, j])), j] > 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 33, 64, 100, 128, 129, 130, 200, 257, 512, 777])
+def test_topk_solver_against_lapack(n):
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n + 5, n)) * np.logspace(0, -4, n)[None, :]
+    q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    g = q @ (a.T @ a) @ q.T
+    g = 0.5 * (g + g.T)
+    k = min(n, 64)
+    (w, v), = _topk(lib, [g], [k])
+    _check_topk(g, w, v, k)
+
+
+def test_topk_solver_batch_of_mixed_sizes_and_ranks():
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    sizes, ks = [512, 40, 300, 512, 7, 131], [64, 40, 17, 128, 1, 100]
+    mats = []
+    for n in sizes:
+        a = rng.standard_normal((2 * n, n)) * np.logspace(0, -5, n)[None, :]
+        mats.append(a.T @ a)
+    for g, k, (w, v) in zip(mats, ks, _topk(lib, mats, ks, k_max=128)):
+        _check_topk(g, w, v, k)
+
+
+def test_topk_solver_volume_gram_matrices_with_noise_floor_clusters():
+    """The matrices the sweep meets: Gram matrices of the chi-capped unfoldings of a noisy volume, a few large
+    eigenvalues over a floor of ~n near-equal ones (gaps ~1e-9 of the largest).  The kept subspace must agree
+    with LAPACK's to the accuracy its conditioning allows: |P - P_ref| <= 50 eps |G| / gap."""
+    lib = _lib.load()
+    x = synthetic_mri((64, 64, 64), seed=3).astype(np.float64)
+    dense = np.empty(x.size)
+    dense[oim.flat_destination(x.shape).reshape(-1)] = x.reshape(-1)
+    mats, work, chi_r = [], dense.reshape(-1, 1), 1
+    for i in range(5, 0, -1):
+        mat = work.reshape(-1, 8 * chi_r)
+        if mat.shape[1] > mat.shape[0]:
+            break
+        g = mat.T @ mat
+        wv, vv = np.linalg.eigh(g)
+        kk = min(32, g.shape[0])
+        if g.shape[0] > 32:
+            mats.append(g)
+        work, chi_r = mat @ vv[:, ::-1][:, :kk], kk
+    assert len(mats) >= 2
+    for g, (w, v) in zip(mats, _topk(lib, mats, [32] * len(mats))):
+        _check_topk(g, w, v, 32)
+        wr, vr = np.linalg.eigh(g)
+        wr, vr = wr[::-1], vr[:, ::-1]
+        gap = (wr[31] - wr[32]) / wr[0]
+        assert np.abs(v @ v.T - vr[:, :32] @ vr[:, :32].T).max() <= 50 * 2.2e-16 / gap + 1e-12
+
+
+def test_topk_solver_degenerate_spectra():
+    """Zero matrix, identity (n-fold eigenvalue), rank one, exact multiplicities, a diagonal matrix (every
+    reflector is the identity) and decoupled identical blocks: orthonormal vectors with small residuals even
+    where the eigenvectors themselves are not unique."""
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    n = 96
+    u = rng.standard_normal(n)
+    q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    lam = np.r_[np.full(10, 5.0), np.full(20, 1.0), np.zeros(n - 30)]
+    blk = rng.standard_normal((8, 8))
+    cases = [(np.zeros((n, n)), 8), (np.eye(n), 8), (np.outer(u, u), 8), ((q * lam) @ q.T, 30), ((q * lam) @ q.T, 12),
+             (np.diag(np.arange(n, 0, -1.0)), 10), (np.kron(np.eye(12), blk @ blk.T), 24), (np.eye(200) * 3.0, 50)]
+    mats = [0.5 * (g + g.T) for g, _ in cases]
+    for g, k, (w, v) in zip(mats, [k for _, k in cases], _topk(lib, mats, [k for _, k in cases])):
+        _check_topk(g, w, v, k, tol_scale=4.0)
+
+
 def test_from_tensors_equals_from_tensor_one_by_one():
     vols = [synthetic_mri((32, 32, 32), seed=s) for s in (1, 2, 3)]
     vols[1] = vols[1] * 0.25  # different scales and spectra inside one batch

@@ -1,0 +1,193 @@
+"""CPU prototype of the direct top-k symmetric eigen-solver the GPU path uses (csrc/eig_tridiag.hip):
+Householder tridiagonalisation -> bisection on a rescaled polynomial Sturm sequence -> inverse iteration with
+pivoted tridiagonal LU from random starts, CholQR between iterations -> back-transformation.
+Validates the arithmetic choices (no divisions in the Sturm chain, fixed 3 iterations, CholQR instead of
+Gram-Schmidt inside clusters) on the Gram matrices of a 256^3 volume and on degenerate inputs."""
+import sys
+import numpy as np
+
+
+def householder_tridiag(A):
+    """Unblocked dsytd2-style reduction (lower), returns d, e, reflectors V (row j: v_j on indices j+1..n-1), tau."""
+    A = A.copy()
+    n = A.shape[0]
+    d = np.zeros(n); e = np.zeros(max(n - 1, 0)); V = np.zeros((n, n)); tau = np.zeros(n)
+    for j in range(n - 1):
+        d[j] = A[j, j]
+        x = A[j + 1:, j].copy()
+        alpha = x[0]
+        sigma = np.dot(x[1:], x[1:])
+        if sigma == 0.0:
+            t = 0.0; beta = alpha; v = np.zeros_like(x); v[0] = 1.0
+        else:
+            beta = -np.copysign(np.sqrt(alpha * alpha + sigma), alpha)
+            t = (beta - alpha) / beta
+            v = x / (alpha - beta); v[0] = 1.0
+        e[j] = beta
+        V[j, j + 1:] = v; tau[j] = t
+        if t != 0.0:
+            S = A[j + 1:, j + 1:]
+            y = S @ v
+            w = t * y - (0.5 * t * t * np.dot(y, v)) * v
+            S -= np.outer(v, w) + np.outer(w, v)
+    d[n - 1] = A[n - 1, n - 1]
+    return d, e, V, tau
+
+
+def sturm_count_poly(d, e2, x):
+    """# eigenvalues < x, multiplication-only three-term recurrence, rescaled every 4 steps (vectorised over x)."""
+    x = np.atleast_1d(x)
+    p1 = np.ones_like(x); p0 = d[0] - x  # p_{-1}... here p1 = p_{i-1}, p0 = p_i after step
+    cnt = (p0 < 0).astype(np.int64)
+    # zero convention: a zero takes the sign opposite to its predecessor => counts as a sign change
+    cnt += (p0 == 0)
+    prev_neg = (p0 < 0) | (p0 == 0)  # sign(p_0 = 1) positive, so "negative" state after a change
+    pm, pc = p1, p0
+    for i in range(1, len(d)):
+        pn = (d[i] - x) * pc - e2[i - 1] * pm
+        # sign of pn with the zero convention: zero => opposite of sign(pc)
+        neg_c = prev_neg
+        neg_n = np.where(pn == 0, ~neg_c, pn < 0)
+        cnt += (neg_n != neg_c)
+        prev_neg = neg_n
+        pm, pc = pc, pn
+        if i % 4 == 0:
+            m = np.maximum(np.abs(pm), np.abs(pc))
+            m = np.where(m == 0, 1.0, m)
+            _, ex = np.frexp(m)
+            s = np.ldexp(1.0, -ex)
+            pm = pm * s; pc = pc * s
+    return cnt
+
+
+def sturm_count_pivot(d, e2, x, pivmin):
+    x = np.atleast_1d(x)
+    q = d[0] - x
+    q = np.where(np.abs(q) < pivmin, -pivmin, q)
+    cnt = (q < 0).astype(np.int64)
+    for i in range(1, len(d)):
+        q = d[i] - x - e2[i - 1] / q
+        q = np.where(np.abs(q) < pivmin, -pivmin, q)
+        cnt += (q < 0)
+    return cnt
+
+
+def bisect_all(d, e, count_fn):
+    """all eigenvalues ascending; T must be scaled to Gershgorin radius <= 1"""
+    n = len(d)
+    e2 = e * e
+    lo = np.full(n, -1.0 - 1e-3); hi = np.full(n, 1.0 + 1e-3)
+    idx = np.arange(n)
+    for it in range(60):
+        mid = 0.5 * (lo + hi)
+        c = count_fn(d, e2, mid)
+        right = c <= idx       # fewer than idx+1 eigenvalues below mid: eigenvalue idx is >= mid
+        lo = np.where(right, mid, lo); hi = np.where(right, hi, mid)
+    return 0.5 * (lo + hi)
+
+
+def tridiag_lu(d, e, mu, eps):
+    """pivoted LU of T - mu I for a vector of shifts mu (k,), arrays (n, k)"""
+    n = len(d); k = len(mu)
+    dd = d[:, None] - mu[None, :]
+    dl = np.repeat(e[:, None], k, 1) if n > 1 else np.zeros((0, k))
+    du = dl.copy()
+    du2 = np.zeros((max(n - 2, 0), k))
+    piv = np.zeros((max(n - 1, 0), k), dtype=bool)
+    for i in range(n - 1):
+        swap = np.abs(dd[i]) < np.abs(dl[i])
+        piv[i] = swap
+        # no swap
+        di = np.where(swap, dl[i], dd[i])
+        di = np.where(di == 0, eps, di)
+        fact = np.where(swap, dd[i], dl[i]) / di
+        new_du_i = np.where(swap, dd[i + 1], du[i])
+        upper_next = np.where(swap, du[i], dd[i + 1])
+        dd[i] = di
+        dd[i + 1] = upper_next - fact * new_du_i
+        if i < n - 2:
+            du2[i] = np.where(swap, du[i + 1], 0.0)
+            du[i + 1] = np.where(swap, -fact * du[i + 1], du[i + 1])
+        du[i] = new_du_i
+        dl[i] = fact
+    if n >= 1:
+        dd[n - 1] = np.where(dd[n - 1] == 0, eps, dd[n - 1])
+    return dl, dd, du, du2, piv
+
+
+def tridiag_solve(lu, b):
+    dl, dd, du, du2, piv = lu
+    x = b.copy()
+    n = x.shape[0]
+    for i in range(n - 1):
+        xi, xi1 = x[i].copy(), x[i + 1].copy()
+        a = np.where(piv[i], xi1, xi)
+        bb = np.where(piv[i], xi, xi1)
+        x[i] = a
+        x[i + 1] = bb - dl[i] * a
+    x[n - 1] = x[n - 1] / dd[n - 1]
+    if n > 1:
+        x[n - 2] = (x[n - 2] - du[n - 2] * x[n - 1]) / dd[n - 2]
+    for i in range(n - 3, -1, -1):
+        x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / dd[i]
+    return x
+
+
+def cholqr(Z):
+    S = Z.T @ Z
+    R = np.linalg.cholesky(S).T
+    return np.linalg.solve(R.T, Z.T).T
+
+
+def topk_eig(G, k, iters=3, count_fn=sturm_count_poly, seed=0):
+    n = G.shape[0]
+    d, e, V, tau = householder_tridiag(G)
+    bound = max(np.max(np.abs(d) + np.abs(np.r_[0, e]) + np.abs(np.r_[e, 0])), 1e-300)
+    ds, es = d / bound, e / bound
+    lam = bisect_all(ds, es, count_fn)[::-1]          # descending, scaled
+    mu = lam[:k]
+    lu = tridiag_lu(ds, es, mu, 2.2e-16)
+    rng = np.random.default_rng(seed)
+    Z = rng.uniform(-1, 1, (n, k))
+    for it in range(iters):
+        Z = tridiag_solve(lu, Z)
+        Z /= np.linalg.norm(Z, axis=0)
+        Z = cholqr(Z)
+    # back-transform: Q = H_0 H_1 ... ; X = Q Z
+    X = Z
+    for j in range(n - 2, -1, -1):
+        v = V[j]
+        X = X - tau[j] * np.outer(v, v @ X)
+    return lam * bound, X
+
+
+def check(name, G, k):
+    n = G.shape[0]
+    w_ref, V_ref = np.linalg.eigh(G); w_ref = w_ref[::-1]; V_ref = V_ref[:, ::-1]
+    for cf, label in ((sturm_count_poly, "poly"), (lambda d, e2, x: sturm_count_pivot(d, e2, x, 1e-300), "pivot")):
+        w, X = topk_eig(G, k, count_fn=cf)
+        scale = max(abs(w_ref[0]), 1e-300)
+        P = X @ X.T; Pr = V_ref[:, :k] @ V_ref[:, :k].T
+        gap = (w_ref[k - 1] - w_ref[k]) / scale if k < n else np.nan
+        print(f"{name:10s} {label:5s} n={n} k={k}: eig err {np.abs(w - w_ref).max() / scale:.1e}  orth {np.abs(X.T @ X - np.eye(k)).max():.1e} "
+              f" resid {np.abs(G @ X - X * w[:k]).max() / scale:.1e}  proj diff {np.abs(P - Pr).max():.1e} (rel gap k|k+1 {gap:.1e})")
+
+
+if __name__ == "__main__":
+    z = np.load(sys.argv[1]) if len(sys.argv) > 1 else {}
+    for key in z:
+        check(key, z[key], 64)
+    rng = np.random.default_rng(1)
+    n = 96
+    check("zero", np.zeros((n, n)), 8)
+    check("identity", np.eye(n), 8)
+    u = rng.standard_normal(n); check("rank1", np.outer(u, u), 8)
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    lam = np.r_[np.full(10, 5.0), np.full(20, 1.0), np.zeros(n - 30)]
+    check("multiples", (Q * lam) @ Q.T, 30)
+    check("multiples", (Q * lam) @ Q.T, 12)
+    a = rng.standard_normal((200, n)) * np.logspace(0, -6, n)
+    check("graded", a.T @ a, 16)
+    check("diag", np.diag(np.arange(n, 0, -1.0)), 10)
+    B = rng.standard_normal((8, 8)); B = B @ B.T
+    check("blockdup", np.kron(np.eye(12), B), 24)
