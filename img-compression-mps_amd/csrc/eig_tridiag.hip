@@ -3,7 +3,8 @@
 //
 //   G = Q T Q^T      Householder tridiagonalisation, unblocked, the rank-2 update of step j-1 applied while
 //                    step j reads the matrix (one pass over the trailing matrix per column)
-//   T  -> w          all n eigenvalues by multi-section on a Sturm sequence (no divisions in the chain)
+//   T  -> w          the k_max largest eigenvalues by 65-section on a Sturm sequence (one wave each, no
+//                    divisions in the chain)
 //   T  -> Z (n x k)  inverse iteration from random starts, pivoted tridiagonal LU, three rounds with a
 //                    Cholesky-QR of the whole block between rounds (clusters need no special casing)
 //   V = Q Z          reflectors replayed on the k columns held in registers
@@ -38,8 +39,6 @@ constexpr int kTailLd = 132;      // LDS row stride of the tail matrix (ld = 4 m
 constexpr int kColsPerWg = 32;    // columns of one workgroup of the column kernel
 constexpr int kMaxK = 128;        // largest number of eigenvectors (Cholesky factor lives in LDS)
 constexpr int kMaxN = 4096;       // three n-vectors of the column kernel live in LDS
-constexpr int kSect = 8;          // lanes per eigenvalue in the multi-section
-constexpr int kInvIters = 3;
 
 struct TrdDesc {       // one per matrix (device array), blockIdx.y selects it
   const double* G_in;  // n x n (ld n)
@@ -63,6 +62,7 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   double* Z;           // [B][n_max][kp] eigenvectors of T
   double* lu;          // [B][4][n_max][kp] dl, 1/d, du, du2 of the pivoted factorisations
   unsigned char* piv;  // [B][n_max][kp]
+  long long* stamps;   // [B][16] wall-clock (100 MHz) marks of the single-workgroup kernels' phases (tools/trd_probe.py)
   int n_max, lda, kp;
 };
 
@@ -136,6 +136,17 @@ __global__ void __launch_bounds__(256) trd_load_kernel(const TrdDesc* __restrict
 //            row j with that update applied -> d_j and the reflector v_j, tau_j, e_j
 //   body   : A[i][c] -= v'[i] w'[c] + w'[i] v'[c];  y[c] += A[i][c] v_j[i]   (i > j)
 // Lane layout of the body: 16 lanes x 16 bytes cover the 32 columns of one row, 4 rows per wave instruction.
+// A launch is a chain of dependent memory round trips, not a bandwidth problem (the trailing matrix of one
+// workgroup is <= 128 KB), so everything whose address is known is requested at once, up front: the
+// workgroup's whole share of the trailing matrix (up to 32 tiles of 16 bytes per lane = 512 rows; more rows
+// stream afterwards), the three n-vectors of the prologue and the five scalars it broadcasts.  The
+// prologue's arithmetic then runs under the flight time of the matrix tiles.
+//   NR: n-vector elements per thread (n <= 256 NR).
+struct __attribute__((aligned(16))) RowVec {  // per-row operands of the body, one 32-byte LDS record
+  double vp, wp, vj, pad;
+};
+
+template <int NR>
 __global__ void __launch_bounds__(256)
 trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
   const TrdDesc& d = desc[blockIdx.y];
@@ -150,96 +161,143 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
   double* Vh = w.Vh + b * w.n_max * lda;
   double* ybuf = w.y + b * 2 * lda;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* vp = lds;               // v'  (reflector of step j - 1)
-  double* wp = lds + w.n_max;     // w'
-  double* vj = lds + 2 * w.n_max; // reflector of this step
-  __shared__ double red[4];
+  RowVec* rv = reinterpret_cast<RowVec*>(lds);  // [n]
+  __shared__ double red_a[4], red_b[4];
   __shared__ double part[4][kColsPerWg];
 
-  // ---- prologue a: w' of step j - 1
+  // ---- every load whose address is known: matrix tiles first (the longest flight)
+  constexpr int PRE = 32;
+  const int q = lane >> 4, p = lane & 15;
+  const int c = c0 + 2 * p;
+  const bool col_ok = c < lda;  // lda is even: c + 1 < lda too; the padding column holds zeros
+  const int first = j + 1 + 4 * wave + q;
+  double2 a[PRE];
+#pragma unroll
+  for (int u = 0; u < PRE; ++u) {
+    const int i = first + 16 * u;
+    a[u] = (i < n && col_ok) ? *reinterpret_cast<const double2*>(A + (int64_t)i * lda + c) : make_double2(0.0, 0.0);
+  }
+  const double* rowj = A + (int64_t)j * lda;
+  double yv[NR], vv[NR], rj[NR];
+  double taup = 0.0, y_j = 0.0, y_j1 = 0.0, v_j1 = 0.0;
+  const double r_j1 = rowj[j + 1];
   if (j >= 1) {
     const double* yprev = ybuf + ((j - 1) & 1) * lda;
     const double* vprev = Vh + (int64_t)(j - 1) * lda;
-    const double taup = w.tau[b * w.n_max + j - 1];
-    double dot = 0.0;
-    for (int i = tid; i < n; i += 256) {
-      const double vv = i >= j ? vprev[i] : 0.0;
-      const double yv = i >= j ? yprev[i] : 0.0;
-      vp[i] = vv;
-      wp[i] = yv;
-      dot = fma(yv, vv, dot);
+    taup = w.tau[b * w.n_max + j - 1];
+    y_j = yprev[j];
+    y_j1 = yprev[j + 1];
+    v_j1 = vprev[j + 1];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int i = tid + 256 * r;
+      const bool in = i >= j && i < n;
+      yv[r] = in ? yprev[i] : 0.0;
+      vv[r] = in ? vprev[i] : 0.0;
     }
-    dot = block_sum<4>(dot, red);
-    const double al = 0.5 * taup * taup * dot;
-    for (int i = tid; i < n; i += 256) wp[i] = taup * wp[i] - al * vp[i];
-    __syncthreads();
+  } else {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) yv[r] = vv[r] = 0.0;
   }
-  // ---- prologue b: row j, updated; d_j, x = row[j+1:], sigma = |x[1:]|^2
-  const double* rowj = A + (int64_t)j * lda;
-  const double vpj = j >= 1 ? vp[j] : 0.0, wpj = j >= 1 ? wp[j] : 0.0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = tid + 256 * r;
+    rj[r] = (i >= j && i < n) ? rowj[i] : 0.0;
+  }
+
+  // ---- prologue a: w' of step j - 1 (one barrier per reduction: each has its own slots)
+  double dot = 0.0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) dot = fma(yv[r], vv[r], dot);
+  dot = wave_sum(dot);
+  if (lane == 0) red_a[wave] = dot;
+  __syncthreads();
+  dot = (red_a[0] + red_a[1]) + (red_a[2] + red_a[3]);
+  const double al = 0.5 * taup * taup * dot;
+  const double wpj = taup * y_j - al;  // v'[j] = 1
+  // ---- prologue b: row j with the update applied; x = row[j + 1:], sigma = |x[1:]|^2
+  double wq[NR];
   double sigma = 0.0;
-  for (int i = tid; i < n; i += 256) {
-    double a = 0.0;
-    if (i >= j) {
-      a = rowj[i];
-      if (j >= 1) a -= vpj * wp[i] + wpj * vp[i];
-    }
-    vj[i] = a;
-    if (i > j + 1) sigma = fma(a, a, sigma);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = tid + 256 * r;
+    wq[r] = taup * yv[r] - al * vv[r];
+    rj[r] -= wq[r] + wpj * vv[r];  // v'[j] w'[i] + w'[j] v'[i]
+    if (i > j + 1 && i < n) sigma = fma(rj[r], rj[r], sigma);
   }
-  sigma = block_sum<4>(sigma, red);
-  const double dj = vj[j], alpha = vj[j + 1];
+  sigma = wave_sum(sigma);
+  if (lane == 0) red_b[wave] = sigma;
+  __syncthreads();
+  sigma = (red_b[0] + red_b[1]) + (red_b[2] + red_b[3]);
+  const double alpha = r_j1 - ((taup * y_j1 - al * v_j1) + wpj * v_j1);
   double beta, tau, scale;
   householder(alpha, sigma, beta, tau, scale);
-  __syncthreads();  // everybody has read vj[j], vj[j + 1]
   const bool writer = (int)blockIdx.x == (j + 1) / kColsPerWg;
-  for (int i = tid; i < lda; i += 256) {
-    double v = 0.0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int i = tid + 256 * r;
     if (i < n) {
-      v = i > j + 1 ? vj[i] * scale : (i == j + 1 ? 1.0 : 0.0);
-      vj[i] = v;
+      const double v = i > j + 1 ? rj[r] * scale : (i == j + 1 ? 1.0 : 0.0);
+      RowVec rec;
+      rec.vp = vv[r];
+      rec.wp = wq[r];
+      rec.vj = v;
+      rec.pad = 0.0;
+      rv[i] = rec;
+      if (writer) Vh[(int64_t)j * lda + i] = v;
+      if (writer && i == j) {
+        w.d[b * w.n_max + j] = rj[r];
+        w.e[b * w.n_max + j] = beta;
+        w.tau[b * w.n_max + j] = tau;
+      }
+    } else if (writer && i < lda) {
+      Vh[(int64_t)j * lda + i] = 0.0;
     }
-    if (writer) Vh[(int64_t)j * lda + i] = v;
-  }
-  if (writer && tid == 0) {
-    w.d[b * w.n_max + j] = dj;
-    w.e[b * w.n_max + j] = beta;
-    w.tau[b * w.n_max + j] = tau;
   }
   __syncthreads();
 
   // ---- body
-  const int q = lane >> 4, p = lane & 15;
-  const int c = c0 + 2 * p;
-  const bool col_ok = c < lda;  // lda is even: c + 1 < lda too; the padding column holds zeros
   double wc0 = 0.0, wc1 = 0.0, vc0 = 0.0, vc1 = 0.0;
   if (j >= 1 && col_ok) {
-    if (c < n) { wc0 = wp[c]; vc0 = vp[c]; }
-    if (c + 1 < n) { wc1 = wp[c + 1]; vc1 = vp[c + 1]; }
+    if (c < n) { wc0 = rv[c].wp; vc0 = rv[c].vp; }
+    if (c + 1 < n) { wc1 = rv[c + 1].wp; vc1 = rv[c + 1].vp; }
   }
   double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+  for (int u = 0; u < PRE; ++u) {
+    const int i = first + 16 * u;
+    if (i < n && col_ok) {
+      const RowVec rec = rv[i];
+      if (j >= 1) {
+        a[u].x -= fma(rec.vp, wc0, rec.wp * vc0);
+        a[u].y -= fma(rec.vp, wc1, rec.wp * vc1);
+        *reinterpret_cast<double2*>(A + (int64_t)i * lda + c) = a[u];
+      }
+      acc0 = fma(a[u].x, rec.vj, acc0);
+      acc1 = fma(a[u].y, rec.vj, acc1);
+    }
+  }
+  // rows beyond the prefetched 512 (orders above 512 + j)
   constexpr int U = 8;
-  const int first = j + 1 + 4 * wave + q;
-  for (int i0 = first; i0 < n; i0 += 16 * U) {
-    double2 a[U];
+  for (int i0 = first + 16 * PRE; i0 < n; i0 += 16 * U) {
+    double2 t[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + 16 * u;
-      a[u] = (i < n && col_ok) ? *reinterpret_cast<const double2*>(A + (int64_t)i * lda + c) : make_double2(0.0, 0.0);
+      t[u] = (i < n && col_ok) ? *reinterpret_cast<const double2*>(A + (int64_t)i * lda + c) : make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + 16 * u;
       if (i < n && col_ok) {
-        const double vji = vj[i];
+        const RowVec rec = rv[i];
         if (j >= 1) {
-          const double vpi = vp[i], wpi = wp[i];
-          a[u].x -= fma(vpi, wc0, wpi * vc0);
-          a[u].y -= fma(vpi, wc1, wpi * vc1);
-          *reinterpret_cast<double2*>(A + (int64_t)i * lda + c) = a[u];
+          t[u].x -= fma(rec.vp, wc0, rec.wp * vc0);
+          t[u].y -= fma(rec.vp, wc1, rec.wp * vc1);
+          *reinterpret_cast<double2*>(A + (int64_t)i * lda + c) = t[u];
         }
-        acc0 = fma(a[u].x, vji, acc0);
-        acc1 = fma(a[u].y, vji, acc1);
+        acc0 = fma(t[u].x, rec.vj, acc0);
+        acc1 = fma(t[u].y, rec.vj, acc1);
       }
     }
   }
@@ -259,13 +317,14 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
 
 // --------------------------------------------------------------------------------------- tail kernel
 // One workgroup per matrix finishes columns J = max(n - 128, 0) .. n - 2 with the trailing matrix in LDS.
-// 512 threads: thread (r, t) = (tid / 4, tid % 4) owns row r of the trailing matrix, columns c = t mod 4.
+// 512 threads: thread (r, t) = (tid / 4, tid % 4) owns row r of the trailing matrix, column pairs t mod 4.
+// Four barriers per column; per-column operands (v', w', v_j) sit in one 32-byte record per column.
 __global__ void __launch_bounds__(512) trd_tail_kernel(const TrdDesc* __restrict__ desc, TrdWork w) {
   const TrdDesc& d = desc[blockIdx.y];
   const int n = d.n;
   const int J = max(n - kTail, 0), m = n - J;
   const int lda = w.lda;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b = blockIdx.y;
   const double* A = w.A + b * w.n_max * lda;
   double* Vh = w.Vh + b * w.n_max * lda;
@@ -274,97 +333,124 @@ __global__ void __launch_bounds__(512) trd_tail_kernel(const TrdDesc* __restrict
   double* ee = w.e + b * w.n_max;
   double* tt = w.tau + b * w.n_max;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* S = lds;                        // [kTail][kTailLd]
-  double* vp = lds + kTail * kTailLd;     // pending update (step jj - 1): v', w'
-  double* wp = vp + kTail;
-  double* vj = wp + kTail;                // reflector of the current step
-  double* yv = vj + kTail;                // S v_j
-  __shared__ double red[8];
+  double* S = lds;                                                 // [kTail][kTailLd]
+  RowVec* cv = reinterpret_cast<RowVec*>(lds + kTail * kTailLd);   // [kTail] {v', w', v_j}
+  __shared__ double red_s[8], red_d[8];
 
   // pending update of the last column launch
-  double taup = 0.0;
   if (J >= 1) {
     const double* yprev = ybuf + ((J - 1) & 1) * lda;
     const double* vprev = Vh + (int64_t)(J - 1) * lda;
-    taup = tt[J - 1];
-    double dot = 0.0;
+    const double taup = tt[J - 1];
+    double dot = 0.0, vv = 0.0, y0 = 0.0;
     if (tid < m) {
-      const double vv = vprev[J + tid], y0 = yprev[J + tid];
-      vp[tid] = vv;
-      wp[tid] = y0;
+      vv = vprev[J + tid];
+      y0 = yprev[J + tid];
       dot = y0 * vv;
     }
-    dot = block_sum<8>(dot, red);
+    dot = wave_sum(dot);
+    if (lane == 0) red_s[wave] = dot;
+    __syncthreads();
+    dot = 0.0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) dot += red_s[x];
     const double al = 0.5 * taup * taup * dot;
-    if (tid < m) wp[tid] = taup * wp[tid] - al * vp[tid];
+    if (tid < m) {
+      cv[tid].vp = vv;
+      cv[tid].wp = taup * y0 - al * vv;
+    }
   } else if (tid < m) {
-    vp[tid] = 0.0;
-    wp[tid] = 0.0;
+    cv[tid].vp = 0.0;
+    cv[tid].wp = 0.0;
   }
   __syncthreads();
   for (int e = tid; e < m * m; e += 512) {
     const int r = e / m, c = e % m;
-    S[r * kTailLd + c] = A[(int64_t)(J + r) * lda + J + c] - (vp[r] * wp[c] + wp[r] * vp[c]);
+    S[r * kTailLd + c] = A[(int64_t)(J + r) * lda + J + c] - (cv[r].vp * cv[c].wp + cv[r].wp * cv[c].vp);
   }
   __syncthreads();
-  if (tid < m) {  // the update is applied: nothing pending
-    vp[tid] = 0.0;
-    wp[tid] = 0.0;
+  if (tid < kTail) {  // the update is applied: nothing pending; columns >= m never contribute
+    cv[tid].vp = 0.0;
+    cv[tid].wp = 0.0;
+    cv[tid].vj = 0.0;
+  }
+  for (int e = tid; e < kTail * kTailLd; e += 512) {
+    const int r = e / kTailLd, c = e % kTailLd;
+    if (r >= m || c >= m) S[e] = 0.0;
   }
   __syncthreads();
 
   const int r = tid >> 2, t = tid & 3;
   for (int jj = 0; jj + 1 < m; ++jj) {
     const int j = J + jj;
-    // row jj with the pending update -> d_j, x, sigma
-    const double vpj = vp[jj], wpj = wp[jj];
-    double sigma = 0.0, a = 0.0;
-    if (tid < m && tid >= jj) {
-      a = S[jj * kTailLd + tid] - (vpj * wp[tid] + wpj * vp[tid]);
+    // ---- A: row jj with the pending update -> x, sigma; alpha and d_j from LDS directly
+    const double vpj = cv[jj].vp, wpj = cv[jj].wp;
+    double a = 0.0, sigma = 0.0;
+    if (tid < m && tid > jj) {
+      a = S[jj * kTailLd + tid] - (vpj * cv[tid].wp + wpj * cv[tid].vp);
       if (tid > jj + 1) sigma = a * a;
     }
-    if (tid < m) vj[tid] = a;
-    sigma = block_sum<8>(sigma, red);
-    const double dj = vj[jj], alpha = vj[jj + 1];
+    sigma = wave_sum(sigma);
+    if (lane == 0) red_s[wave] = sigma;
+    const double alpha = S[jj * kTailLd + jj + 1] - (vpj * cv[jj + 1].wp + wpj * cv[jj + 1].vp);
+    __syncthreads();
+    sigma = 0.0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) sigma += red_s[x];
     double beta, tau, scale;
     householder(alpha, sigma, beta, tau, scale);
-    __syncthreads();  // everybody has read vj[jj], vj[jj + 1]
-    if (tid < m) vj[tid] = tid > jj + 1 ? a * scale : (tid == jj + 1 ? 1.0 : 0.0);
+    // ---- B: reflector
+    const double vme = tid > jj + 1 ? a * scale : (tid == jj + 1 ? 1.0 : 0.0);
+    if (tid < m) cv[tid].vj = vme;
     if (tid == 0) {
-      dd[j] = dj;
+      dd[j] = S[jj * kTailLd + jj] - 2.0 * vpj * wpj;
       ee[j] = beta;
       tt[j] = tau;
     }
     __syncthreads();
-    for (int i = tid; i < lda; i += 512) Vh[(int64_t)j * lda + i] = (i >= J && i < n) ? vj[i - J] : 0.0;
-    // one pass: apply the pending update, accumulate y = S v_j (rows and columns > jj)
+    for (int i = tid; i < lda; i += 512) Vh[(int64_t)j * lda + i] = (i >= J && i < n) ? cv[i - J].vj : 0.0;
+    // ---- C: one pass: apply the pending update, y = S v_j (rows and columns > jj), pairs of columns
     double acc = 0.0;
     if (r < m && r > jj) {
-      const double vpr = vp[r], wpr = wp[r];
+      const RowVec me = cv[r];
       double* row = S + r * kTailLd;
-      for (int c = jj + 1 + t; c < m; c += 4) {
-        const double s = row[c] - (vpr * wp[c] + wpr * vp[c]);
-        row[c] = s;
-        acc = fma(s, vj[c], acc);
+      const int it0 = (jj + 1) >> 3;
+#pragma unroll 4
+      for (int it = it0; it < kTail / 8; ++it) {
+        const int c = 2 * (t + 4 * it);
+        // columns <= jj inside the first pair block are finished: their entries are never read again and
+        // v_j is zero there, so they may be updated like the others
+        double2 sv = *reinterpret_cast<double2*>(row + c);
+        const RowVec c0v = cv[c], c1v = cv[c + 1];
+        sv.x -= me.vp * c0v.wp + me.wp * c0v.vp;
+        sv.y -= me.vp * c1v.wp + me.wp * c1v.vp;
+        acc = fma(sv.x, c0v.vj, acc);
+        acc = fma(sv.y, c1v.vj, acc);
+        *reinterpret_cast<double2*>(row + c) = sv;
       }
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
-    if (t == 0 && r < m) yv[r] = r > jj ? acc : 0.0;
+    const double vjr = r < kTail ? cv[r].vj : 0.0;
+    double dot = (t == 0 && r < m && r > jj) ? acc * vjr : 0.0;
+    dot = wave_sum(dot);
+    if (lane == 0) red_d[wave] = dot;
     __syncthreads();
-    double dot = 0.0;
-    if (tid < m) dot = yv[tid] * vj[tid];
-    dot = block_sum<8>(dot, red);
+    dot = 0.0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) dot += red_d[x];
+    // ---- D: w of this step becomes the pending update
     const double al = 0.5 * tau * tau * dot;
-    if (tid < m) {
-      wp[tid] = tau * yv[tid] - al * vj[tid];
-      vp[tid] = vj[tid];
+    if (t == 0 && r < m) {
+      const double yr = r > jj ? acc : 0.0;
+      cv[r].wp = tau * yr - al * vjr;
+      cv[r].vp = vjr;
     }
     __syncthreads();
   }
   if (tid == 0) {
     const int jj = m - 1;
-    dd[n - 1] = S[jj * kTailLd + jj] - 2.0 * vp[jj] * wp[jj];
+    dd[n - 1] = S[jj * kTailLd + jj] - 2.0 * cv[jj].vp * cv[jj].wp;
     ee[n - 1] = 0.0;
     tt[n - 1] = 0.0;
   }
@@ -372,41 +458,53 @@ __global__ void __launch_bounds__(512) trd_tail_kernel(const TrdDesc* __restrict
 }
 
 // ----------------------------------------------------------------------------------------- bisection
-// # eigenvalues of the scaled T below x: sign changes of p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}, a
-// zero taking the sign opposite to its predecessor.  No division in the dependent chain; the pair is
-// rescaled by a power of two every fourth step (|d - x| <= 2, e^2 <= 1 after scaling by the Gershgorin
-// bound, so four steps stay far inside the fp64 range).  de2[i] = (d_i, e_{i-1}^2) in LDS.
-__device__ __forceinline__ int sturm_count(const double2* __restrict__ de2, int n, double x) {
-  double pm = 1.0, pc = de2[0].x - x;
-  bool neg = !(pc > 0.0);  // zero counts as a change from p_{-1} = 1
-  int cnt = neg ? 1 : 0;
-  for (int i = 1; i < n; ++i) {
-    const double2 v = de2[i];
-    const double pn = fma(v.x - x, pc, -v.y * pm);
-    const bool neg_n = pn == 0.0 ? !neg : pn < 0.0;
-    cnt += neg_n != neg;
-    neg = neg_n;
-    pm = pc;
-    pc = pn;
-    if ((i & 3) == 0) {
-      const double mx = fmax(fabs(pm), fabs(pc));
-      int ex = 0;
-      if (mx > 0.0) (void)frexp(mx, &ex);
-      pm = ldexp(pm, -ex);
-      pc = ldexp(pc, -ex);
+// # eigenvalues of the scaled T below x = sign changes of p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}.
+// No division in the dependent chain; the pair is rescaled by a power of two every fourth step (|d - x| <= 2,
+// e^2 <= 1 after scaling by the Gershgorin bound, so four steps stay far inside the fp64 range).
+// An exact zero p_i needs no special case as long as e_i^2 > 0: p_{i+1} = -e_i^2 p_{i-1} then has the sign
+// opposite to p_{i-1}, one change whatever sign the zero is given.  e^2 is therefore kept >= 2^-200 (a
+// perturbation of 2^-100 |T| of a sub-diagonal entry; exactly decoupled blocks would otherwise let the
+// sequence die at zero).  de2[i] = (d_i, e_{i-1}^2) in LDS, padded to a multiple of 16 with (4, 2^-200): a
+// padding step multiplies p by 4 - x > 0 and changes no sign.  Sixteen records are fetched ahead of the
+// chain that consumes them (the LDS latency is off the critical path).
+constexpr double kE2Floor = 0x1p-200;
+__device__ __forceinline__ int sturm_count(const double2* __restrict__ de2, int n16, double x) {
+  double pm = 0.0, pc = 1.0;  // p_{-2}, p_{-1}
+  int hp = 0;                 // high word (sign) of p_{-1}
+  unsigned cnt = 0;
+  for (int i0 = 0; i0 < n16; i0 += 16) {
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = de2[i0 + u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const double pn = fma(v[u].x - x, pc, -v[u].y * pm);
+      const int hn = __double2hiint(pn);
+      cnt += (unsigned)(hn ^ hp) >> 31;
+      hp = hn;
+      pm = pc;
+      pc = pn;
+      if ((u & 3) == 3) {
+        const double mx = fmax(fabs(pm), fabs(pc));
+        const int ex = mx > 0.0 ? ilogb(mx) : 0;
+        pm = ldexp(pm, -ex);
+        pc = ldexp(pc, -ex);
+      }
     }
   }
-  return cnt;
+  return (int)cnt;
 }
 
-// grid (ceil(n_max * kSect / 256), B): groups of kSect lanes find one eigenvalue each by multi-section
-__global__ void __launch_bounds__(256) trd_bisect_kernel(const TrdDesc* __restrict__ desc, TrdWork w) {
+// grid (ceil(k_max / 4), B): one WAVE per wanted eigenvalue (the k_max largest), 65-section: every lane counts
+// at one interior point, a ballot tells how many points lie below the eigenvalue.  Ten rounds shrink the
+// Gershgorin interval by 65^10 = 1.3e18.  Eigenvalues beyond k_max are not computed: w is zero there.
+__global__ void __launch_bounds__(256) trd_bisect_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int k_max) {
   const TrdDesc& d = desc[blockIdx.y];
   const int n = d.n;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b = blockIdx.y;
-  const int first = blockIdx.x * (256 / kSect);
-  if (first >= n) return;
+  const int kk = min(k_max, n);
+  if ((int)blockIdx.x * 4 >= kk) return;
   const double* dd = w.d + b * w.n_max;
   const double* ee = w.e + b * w.n_max;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -418,37 +516,38 @@ __global__ void __launch_bounds__(256) trd_bisect_kernel(const TrdDesc* __restri
     g = fmax(g, fabs(dd[i]) + (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i + 1 < n ? fabs(ee[i]) : 0.0));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) g = fmax(g, __shfl_xor(g, off, 64));
-  if ((tid & 63) == 0) red[tid >> 6] = g;
+  if (lane == 0) red[wave] = g;
   __syncthreads();
   const double bound = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
   const double inv = bound > 0.0 ? 1.0 / bound : 0.0;
-  for (int i = tid; i < n; i += 256) {
-    const double es = i > 0 ? ee[i - 1] * inv : 0.0;
-    de2[i] = make_double2(dd[i] * inv, es * es);
+  const int n16 = (n + 15) & ~15;
+  for (int i = tid; i < n16; i += 256) {
+    const double es = (i > 0 && i < n) ? ee[i - 1] * inv : 0.0;
+    de2[i] = i < n ? make_double2(dd[i] * inv, i > 0 ? fmax(es * es, kE2Floor) : 0.0) : make_double2(4.0, kE2Floor);
   }
   __syncthreads();
-  const int grp = tid / kSect, s = tid % kSect;
-  const int m = first + grp;          // ascending index of this group's eigenvalue
-  const bool live = m < n;
-  double lo = -1.001, hi = 1.001;
-  // 2.002 / 9^18 = 1.3e-17: below the spacing of fp64 numbers at the bound
-  for (int round = 0; round < 18; ++round) {
-    const double h = (hi - lo) * (1.0 / (kSect + 1));
-    const double x = lo + h * (s + 1);
-    const int cnt = live ? sturm_count(de2, n, x) : 0;
-    // points whose count is <= m lie at or below the eigenvalue
-    const unsigned long long bal = __ballot(cnt <= m);
-    const int shift = (tid & 63) - s;
-    const int below = __popcll((bal >> shift) & ((1ull << kSect) - 1));
-    lo = lo + h * below;
-    hi = lo + h;
+  const int md = blockIdx.x * 4 + wave;  // descending index of this wave's eigenvalue
+  if (md < kk) {
+    const int m = n - 1 - md;            // ascending index
+    double lo = -1.001, hi = 1.001;
+    for (int round = 0; round < 10; ++round) {
+      const double h = (hi - lo) * (1.0 / 65.0);
+      const int cnt = sturm_count(de2, n16, lo + h * (lane + 1));
+      // points whose count is <= m lie at or below the eigenvalue
+      const int below = __popcll(__ballot(cnt <= m));
+      lo = lo + h * below;
+      hi = lo + h;
+    }
+    if (lane == 0) {
+      const double lam = 0.5 * (lo + hi);
+      w.lam[b * w.n_max + md] = lam;
+      d.w_out[md] = lam * bound;
+    }
   }
-  if (live && s == 0) {
-    const double lam = 0.5 * (lo + hi);
-    w.lam[b * w.n_max + (n - 1 - m)] = lam;
-    d.w_out[n - 1 - m] = lam * bound;
+  if (blockIdx.x == 0) {
+    for (int i = kk + tid; i < n; i += 256) d.w_out[i] = 0.0;
+    if (tid == 0) w.bound[b] = bound;
   }
-  if (blockIdx.x == 0 && tid == 0) w.bound[b] = bound;
 }
 
 // ------------------------------------------------------------------------- inverse iteration + CholQR
@@ -458,9 +557,15 @@ __device__ __forceinline__ double hash_uniform(unsigned a, unsigned b) {
   return (double)x * (2.0 / 4294967296.0) - 1.0 + 1.1e-10;  // never exactly zero
 }
 
-// One workgroup (512 threads) per matrix.  Threads c < k factor T - lam_c I (pivoted, dgttrf order) and solve;
-// the whole workgroup orthonormalises the block: S = Z^T Z (f64 MFMA from global), Cholesky in LDS,
-// Z <- Z L^-T row by row.
+// One workgroup (512 threads) per matrix.  Threads c < k factor T - lam_c I (pivoted, dgttrf order) and solve
+// twice from a random start; no orthogonalisation in between (columns of a numerically multiple eigenvalue
+// stay independent because their starts are), then the whole workgroup orthonormalises the block twice:
+// S = Z^T Z (f64 MFMA from global), Cholesky in LDS, Z <- Z L^-T row by row.  Measured on the CPU prototype
+// (tools/scratch/tridiag_proto.py): two solves + two Cholesky-QR passes give 2e-15 orthogonality and 3e-16
+// residuals on the volume Gram matrices and 5e-15 on exact 10- / 20-fold eigenvalues; a third solve makes
+// the columns of a multiple eigenvalue more parallel and costs a digit.
+// The recurrences are sequential in i and run on k <= 128 lanes: their operands are fetched one chunk of
+// CH steps ahead of the chain that consumes them (a global access costs more than a chunk of the chain).
 __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ desc, TrdWork w) {
   TrdDesc& d = desc[blockIdx.y];
   const int n = d.n, k = d.k, kp = w.kp;
@@ -481,95 +586,171 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   const double bound = w.bound[b];
   const double inv = bound > 0.0 ? 1.0 / bound : 0.0;
   constexpr double kEps = 2.220446049250313e-16;
+  constexpr int CH = 8;
 
-  // ---- factorisation, one thread per shift (scaled T: |T| <= 1)
+  // scaled T, te[i] = (d_i, e_i) / bound, in the LDS the Cholesky factor will use later: only the
+  // factorisation reads it, and that is over before the first S is stored
+  double2* te = reinterpret_cast<double2*>(lds);
+  long long* stamp = w.stamps + b * 16;
+  if (tid == 0) stamp[0] = wall_clock64();
+  for (int i = tid; i < n; i += 512) te[i] = make_double2(dd[i] * inv, i + 1 < n ? ee[i] * inv : 0.0);
+  __syncthreads();
   if (tid < k) {
     const int c = tid;
     const double mu = w.lam[b * w.n_max + c];
-    double di = dd[0] * inv - mu;            // current diagonal
-    double ui = n > 1 ? ee[0] * inv : 0.0;   // current super-diagonal du[i]
-    for (int i = 0; i + 1 < n; ++i) {
-      const double li = ee[i] * inv;                          // sub-diagonal below row i
-      const double dn = dd[i + 1] * inv - mu;                 // d[i + 1] before elimination
-      const double un = i + 2 < n ? ee[i + 1] * inv : 0.0;    // du[i + 1] before elimination
-      const bool swap = fabs(di) < fabs(li);
-      double piv = swap ? li : di;
-      if (piv == 0.0) piv = kEps;
-      const double rp = fast_rcp<2>(piv);
-      const double fact = (swap ? di : li) * rp;
-      const double du_i = swap ? dn : ui;
-      const double up = swap ? ui : dn;
-      const int64_t o = (int64_t)i * kp + c;
-      DL[o] = fact;
-      DI[o] = rp;
-      DU[o] = du_i;
-      DU2[o] = swap ? un : 0.0;
-      PV[o] = swap ? 1 : 0;
-      di = fma(-fact, du_i, up);
-      ui = swap ? -fact * un : un;
+    // ---- factorisation (scaled T: |T| <= 1) fused with the first forward sweep on the random start
+    double di = te[0].x - mu;             // current diagonal
+    double ui = te[0].y;                  // current super-diagonal du[i]
+    double xi = hash_uniform(0u, (unsigned)c);
+    for (int i0 = 0; i0 + 1 < n; i0 += CH) {
+      double2 t0[CH + 1];
+#pragma unroll
+      for (int u = 0; u <= CH; ++u) t0[u] = te[min(i0 + u + 1, n - 1)];
+      double li = te[i0].y;               // sub-diagonal below row i0 (= e_i0)
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int i = i0 + u;
+        if (i + 1 < n) {
+          const double dn = t0[u].x - mu;                    // d[i + 1] before elimination
+          const double un = i + 2 < n ? t0[u].y : 0.0;       // du[i + 1] before elimination
+          const bool swap = fabs(di) < fabs(li);
+          double piv = swap ? li : di;
+          if (piv == 0.0) piv = kEps;
+          const double rp = fast_rcp<2>(piv);
+          const double fact = (swap ? di : li) * rp;
+          const double du_i = swap ? dn : ui;
+          const double up = swap ? ui : dn;
+          const int64_t o = (int64_t)i * kp + c;
+          DL[o] = fact;
+          DI[o] = rp;
+          DU[o] = du_i;
+          DU2[o] = swap ? un : 0.0;
+          PV[o] = swap ? 1 : 0;
+          di = fma(-fact, du_i, up);
+          ui = swap ? -fact * un : un;
+          li = t0[u].y;                                      // e_{i+1}: sub-diagonal below row i + 1
+          const double xn = hash_uniform((unsigned)(i + 1), (unsigned)c);
+          const double top = swap ? xn : xi;
+          const double bot = swap ? xi : xn;
+          Z[o] = top;
+          xi = fma(-fact, top, bot);
+        }
+      }
     }
     if (di == 0.0) di = kEps;
     DI[(int64_t)(n - 1) * kp + c] = fast_rcp<2>(di);
-  }
-  // ---- random start (all columns of the padded block: the pad stays zero)
-  for (int e = tid; e < n * kp; e += 512) {
-    const int i = e / kp, c = e % kp;
-    Z[e] = c < k ? hash_uniform((unsigned)i, (unsigned)c) : 0.0;
-  }
-  __syncthreads();
+    if (tid == 0) stamp[1] = wall_clock64();
 
-  for (int it = 0; it < kInvIters; ++it) {
-    // ---- solve (T - mu I) x = z, normalise
-    if (tid < k) {
-      const int c = tid;
-      double xi = Z[c];
-      for (int i = 0; i + 1 < n; ++i) {
-        const int64_t o = (int64_t)i * kp + c;
-        const double xn = Z[o + kp];
-        const bool swap = PV[o] != 0;
-        const double top = swap ? xn : xi;
-        const double bot = swap ? xi : xn;
-        Z[o] = top;
-        xi = fma(-DL[o], top, bot);
+    for (int it = 0; it < 2; ++it) {
+      if (it > 0) {
+        // ---- forward sweep of the second solve: x <- L^-1 P x, operands one chunk ahead
+        xi = Z[c];
+        double zn[CH], fn[CH];
+        bool sn[CH];
+        auto fetch_f = [&](int i0) {
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int64_t o = (int64_t)min(i0 + u, n - 2) * kp + c;
+            zn[u] = Z[o + kp];
+            fn[u] = DL[o];
+            sn[u] = PV[o] != 0;
+          }
+        };
+        if (n > 1) fetch_f(0);
+        for (int i0 = 0; i0 + 1 < n; i0 += CH) {
+          double zl[CH], fl[CH];
+          bool sw[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            zl[u] = zn[u];
+            fl[u] = fn[u];
+            sw[u] = sn[u];
+          }
+          if (i0 + CH + 1 < n) fetch_f(i0 + CH);
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int i = i0 + u;
+            if (i + 1 < n) {
+              const double top = sw[u] ? zl[u] : xi;
+              const double bot = sw[u] ? xi : zl[u];
+              Z[(int64_t)i * kp + c] = top;
+              xi = fma(-fl[u], top, bot);
+            }
+          }
+        }
       }
-      double x2 = 0.0, x1;
-      x1 = xi * DI[(int64_t)(n - 1) * kp + c];
+      // ---- back substitution with U (d, du, du2), operands one chunk ahead; the result grows by ~1/eps
+      //      per solve and is not rescaled (two solves stay far inside the fp64 range)
+      double x2 = 0.0, x1 = xi * DI[(int64_t)(n - 1) * kp + c];
       Z[(int64_t)(n - 1) * kp + c] = x1;
-      double ss = x1 * x1;
-      for (int i = n - 2; i >= 0; --i) {
-        const int64_t o = (int64_t)i * kp + c;
-        const double x0 = (Z[o] - DU[o] * x1 - DU2[o] * x2) * DI[o];
-        Z[o] = x0;
-        ss = fma(x0, x0, ss);
-        x2 = x1;
-        x1 = x0;
+      double zn[CH], un_[CH], u2n[CH], in_[CH];
+      auto fetch_b = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int64_t o = (int64_t)max(i0 - u, 0) * kp + c;
+          zn[u] = Z[o];
+          un_[u] = DU[o];
+          u2n[u] = DU2[o];
+          in_[u] = DI[o];
+        }
+      };
+      if (n > 1) fetch_b(n - 2);
+      for (int i0 = n - 2; i0 >= 0; i0 -= CH) {
+        double zl[CH], ul[CH], u2l[CH], il[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          zl[u] = zn[u];
+          ul[u] = un_[u];
+          u2l[u] = u2n[u];
+          il[u] = in_[u];
+        }
+        if (i0 - CH >= 0) fetch_b(i0 - CH);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int i = i0 - u;
+          if (i >= 0) {
+            const double x0 = (zl[u] - ul[u] * x1 - u2l[u] * x2) * il[u];
+            Z[(int64_t)i * kp + c] = x0;
+            x2 = x1;
+            x1 = x0;
+          }
+        }
       }
-      const double sc = fast_rsqrt<2>(ss);
-      for (int i = 0; i < n; ++i) Z[(int64_t)i * kp + c] *= sc;
     }
-    __syncthreads();
-    // ---- S = Z^T Z, 16 x 16 tiles (ta <= tb) on f64 MFMA, operands straight from global / L2
+  }
+  // pad columns of the block stay zero
+  if (k < kp)
+    for (int e = tid; e < n * (kp - k); e += 512) Z[(int64_t)(e / (kp - k)) * kp + k + e % (kp - k)] = 0.0;
+  __syncthreads();
+  if (tid == 0) stamp[2] = wall_clock64();
+
+  for (int pass = 0; pass < 2; ++pass) {
+    // ---- S = Z^T Z, 16 x 16 tiles (ta <= tb) on f64 MFMA, operands straight from global / L2,
+    //      eight k-steps of operands requested before the MFMAs that consume them
     const int nt = k16 / 16, ntiles = nt * (nt + 1) / 2;
     for (int tile = wave; tile < ntiles; tile += 8) {
-      int ta = 0, u = tile;
-      while (u >= nt - ta) {
-        u -= nt - ta;
+      int ta = 0, u0 = tile;
+      while (u0 >= nt - ta) {
+        u0 -= nt - ta;
         ++ta;
       }
-      const int tb = ta + u;
+      const int tb = ta + u0;
       const int li = lane & 15, lk = lane >> 4;
       f64x4 acc = {0.0, 0.0, 0.0, 0.0};
       const double* za = Z + ta * 16 + li;
       const double* zb = Z + tb * 16 + li;
-      int i0 = 0;
-      for (; i0 + 4 <= n; i0 += 4) {
-        const int64_t o = (int64_t)(i0 + lk) * kp;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[o], zb[o], acc, 0, 0, 0);
-      }
-      if (i0 < n) {
-        const bool ok = i0 + lk < n;
-        const int64_t o = (int64_t)(ok ? i0 + lk : 0) * kp;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? za[o] : 0.0, ok ? zb[o] : 0.0, acc, 0, 0, 0);
+      for (int i0 = 0; i0 < n; i0 += 32) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + 4 * u + lk;
+          const bool ok = i < n;
+          const int64_t o = (int64_t)(ok ? i : 0) * kp;
+          av[u] = ok ? za[o] : 0.0;
+          bv[u] = ok ? zb[o] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -579,6 +760,7 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
       }
     }
     __syncthreads();
+    if (tid == 0) stamp[3 + 3 * pass] = wall_clock64();
     // ---- Cholesky S = L L^T, left-looking by columns (lower triangle of Ls), rows >= k untouched
     for (int jc = 0; jc < k; ++jc) {
       double v = 0.0;
@@ -601,6 +783,7 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
       }
       __syncthreads();
     }
+    if (tid == 0) stamp[4 + 3 * pass] = wall_clock64();
     // ---- Z <- Z L^-T : row i, z_c = (z_c - sum_{a<c} z_a L[c][a]) / L[c][c]; 32-column register blocks
     for (int i = tid; i < n; i += 512) {
       double* zr = Z + (int64_t)i * kp;
@@ -630,15 +813,21 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
       }
     }
     __syncthreads();
+    if (tid == 0) stamp[5 + 3 * pass] = wall_clock64();
   }
 }
 
 // ------------------------------------------------------------------------------------ back-transform
 // V = H_0 H_1 ... H_{n-2} Z on k columns.  A column lives in the registers of SEG lanes (row i in lane
-// i mod SEG, slot i / SEG), so v^T z is a shuffle reduction and a reflector costs no barrier and no LDS.
-// grid (ceil(k / (256 / SEG)), B), 256 threads.
-template <int SEG, int R>
+// i mod SEG, slot i / SEG), so v^T z is a shuffle reduction and a reflector costs no barrier.  Reflectors
+// come through LDS in blocks of RB rows of Vh, double-buffered: the global loads of block t + 1 are in
+// flight while block t is applied (a reflector takes ~0.1 us to apply, a global access several times that).
+// grid (ceil(k / (256 / SEG)), B), 256 threads; LDS 2 * RB * SEG * R doubles.
+template <int SEG, int R, int RB>
 __global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict__ desc, TrdWork w) {
+  constexpr int NP = SEG * R;             // padded order
+  constexpr int PER = RB * NP / 256;      // doubles per thread and block
+  static_assert(RB * NP % 256 == 0, "block must divide over the workgroup");
   const TrdDesc& d = desc[blockIdx.y];
   const int n = d.n, k = d.k, kp = w.kp, lda = w.lda;
   const int tid = threadIdx.x;
@@ -650,39 +839,61 @@ __global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict
   const double* Z = w.Z + b * w.n_max * kp;
   const double* Vh = w.Vh + b * w.n_max * lda;
   const double* tt = w.tau + b * w.n_max;
-  double x[R], v[R], vn[R];
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // [2][RB][NP]
+  __shared__ double taus[2][RB];
+  double x[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = seg + SEG * r;
     x[r] = (live && i < n) ? Z[(int64_t)i * kp + c] : 0.0;
   }
-  int j = n - 2;
-  if (j >= 0) {
+  // block t holds reflectors j = jtop - t RB - q, q = 0..RB-1 (j < 0: identity)
+  const int jtop = n - 2;
+  const int nblocks = jtop >= 0 ? (jtop + RB) / RB : 0;
+  double stage[PER];
+  auto fetch = [&](int t) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = seg + SEG * r;
-      vn[r] = i < n ? Vh[(int64_t)j * lda + i] : 0.0;
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u, qq = e / NP, i = e % NP;
+      const int j = jtop - t * RB - qq;
+      stage[u] = (j >= 0 && i < n) ? Vh[(int64_t)j * lda + i] : 0.0;
     }
-  }
-  for (; j >= 0; --j) {
+  };
+  auto commit = [&](int t) {
+    double* buf = lds + (t & 1) * RB * NP;
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = vn[r];
-    if (j >= 1) {
+    for (int u = 0; u < PER; ++u) buf[tid + 256 * u] = stage[u];
+    if (tid < RB) {
+      const int j = jtop - t * RB - tid;
+      taus[t & 1][tid] = j >= 0 ? tt[j] : 0.0;
+    }
+  };
+  if (nblocks > 0) {
+    fetch(0);
+    commit(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nblocks; ++t) {
+    if (t + 1 < nblocks) fetch(t + 1);
+    const double* buf = lds + (t & 1) * RB * NP;
+#pragma unroll
+    for (int qq = 0; qq < RB; ++qq) {
+      const double* v = buf + qq * NP + seg;
+      double vr[R];
+      double s = 0.0;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int i = seg + SEG * r;
-        vn[r] = i < n ? Vh[(int64_t)(j - 1) * lda + i] : 0.0;
+        vr[r] = v[SEG * r];
+        s = fma(vr[r], x[r], s);
       }
+#pragma unroll
+      for (int off = SEG / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      s *= taus[t & 1][qq];
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[r] = fma(-s, vr[r], x[r]);
     }
-    const double tau = tt[j];
-    double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) s = fma(v[r], x[r], s);
-#pragma unroll
-    for (int off = SEG / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    s *= tau;
-#pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = fma(-s, v[r], x[r]);
+    if (t + 1 < nblocks) commit(t + 1);  // the other buffer: its readers finished before the last barrier
+    __syncthreads();
   }
   // sign convention of the library: the largest-magnitude component is positive
   double best = 0.0, val = 0.0;
@@ -740,7 +951,7 @@ __global__ void trd_setk_kernel(TrdDesc* __restrict__ desc, RankChunk chunk, int
 // ------------------------------------------------------------------------------------------ host side
 struct TrdLayout {
   int64_t n_max, lda, kp;
-  int64_t off_a, off_vh, off_y, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, total;
+  int64_t off_a, off_vh, off_y, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, total;
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -766,6 +977,7 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_lu = take(batch * 4 * n_max * l.kp * 8);
   l.off_piv = take(batch * n_max * l.kp);
   l.off_desc = take(batch * (int64_t)sizeof(TrdDesc));
+  l.off_stamps = take(batch * 16 * 8);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -784,13 +996,16 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.Z = (double*)(base + l.off_z);
   w.lu = (double*)(base + l.off_lu);
   w.piv = (unsigned char*)(base + l.off_piv);
+  w.stamps = (long long*)(base + l.off_stamps);
   w.n_max = (int)l.n_max;
   w.lda = (int)l.lda;
   w.kp = (int)l.kp;
   return w;
 }
 
-constexpr size_t kTailLds = ((size_t)kTail * kTailLd + 4 * kTail) * sizeof(double);
+// inverse-iteration kernel: Cholesky factor [128][129], aliased by the scaled tridiagonal as (d, e) pairs
+constexpr int kInvitLdsMax = kMaxK * (kMaxK + 1) * 8;  // >= kMaxN * 16
+constexpr size_t kTailLds = ((size_t)kTail * kTailLd + 4 * kTail) * sizeof(double);  // matrix + RowVec[kTail]
 
 // kernels that need more than 64 KB of dynamic LDS are opted in once per device
 int trd_opt_in() {
@@ -802,10 +1017,10 @@ int trd_opt_in() {
   if (dev < 0 || dev >= 64 || done[dev]) return NDMPS_OK;
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_tail_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLds));
-  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_column_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kMaxN * 8));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_column_kernel<16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxN * (int)sizeof(RowVec)));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_invit_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxK * (kMaxK + 1) * 8));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
   done[dev] = true;
   return NDMPS_OK;
 }
@@ -823,6 +1038,11 @@ int trd_check_sizes(int batch, const int64_t* h_n, int64_t& n_max) {
 
 }  // namespace
 
+// phase marks of the inverse-iteration kernel of matrix b (16 x int64, 100 MHz): profiling aid
+extern "C" int64_t ndmps_syevd_topk_stamps_offset(int64_t n_max, int batch, int64_t k_max) {
+  if (n_max <= 0 || n_max > kMaxN || batch <= 0 || k_max <= 0 || k_max > kMaxK) return -1;
+  return trd_layout(n_max, batch, std::min(k_max, n_max)).off_stamps;
+}
 extern "C" int64_t ndmps_syevd_topk_max_n(void) { return kMaxN; }
 extern "C" int64_t ndmps_syevd_topk_max_k(void) { return kMaxK; }
 
@@ -831,7 +1051,8 @@ extern "C" int64_t ndmps_syevd_topk_workspace_bytes(int64_t n_max, int batch, in
   return trd_layout(n_max, batch, std::min(k_max, n_max)).total;
 }
 
-// Phase 1: tridiagonalise and deliver all eigenvalues (descending) in d_w.  Asynchronous on `stream`.
+// Phase 1: tridiagonalise and deliver the min(k_max, n) largest eigenvalues (descending) in d_w, zeros behind
+// them.  Asynchronous on `stream`.
 extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t stride_G, const int64_t* h_n,
                                            double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
                                            int64_t k_max, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
@@ -870,12 +1091,16 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
   const int load_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * l.lda, 256), 512);
   hipLaunchKernelGGL(trd_load_kernel, dim3(load_grid, B), dim3(256), 0, s, desc, w);
   const int W = (int)ndmps::ceil_div(n_max, kColsPerWg);
-  const size_t col_lds = (size_t)3 * n_max * sizeof(double);
-  for (int j = 0; j < n_max - kTail; ++j)
-    hipLaunchKernelGGL(trd_column_kernel, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
+  const size_t col_lds = (size_t)n_max * sizeof(RowVec);
+  auto column = n_max <= 512    ? trd_column_kernel<2>
+                : n_max <= 1024 ? trd_column_kernel<4>
+                : n_max <= 2048 ? trd_column_kernel<8>
+                                : trd_column_kernel<16>;
+  for (int j = 0; j < n_max - kTail; ++j) hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
   hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
-  const int bis_grid = (int)ndmps::ceil_div(n_max * kSect, 256);
-  hipLaunchKernelGGL(trd_bisect_kernel, dim3(bis_grid, B), dim3(256), (size_t)n_max * 16, s, desc, w);
+  const int kk = (int)std::min(k_max, n_max);
+  hipLaunchKernelGGL(trd_bisect_kernel, dim3(ndmps::ceil_div(kk, 4), B), dim3(256),
+                     (size_t)ndmps::round_up(n_max, 16) * 16, s, desc, w, kk);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }
@@ -911,21 +1136,20 @@ extern "C" int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const
     hipLaunchKernelGGL(trd_setk_kernel, dim3(1), dim3(256), 0, s, desc, chunk, base, count);
   }
   const int k16 = (kk + 15) & ~15;
-  hipLaunchKernelGGL(trd_invit_kernel, dim3(1, B), dim3(512), (size_t)k16 * (k16 + 1) * 8, s, desc, w);
-  // rows per lane of the back-transform: n <= SEG * R
+  hipLaunchKernelGGL(trd_invit_kernel, dim3(1, B), dim3(512), std::max((size_t)k16 * (k16 + 1) * 8, (size_t)n_max * 16), s, desc,
+                     w);
+  // rows per lane of the back-transform: n <= SEG * R; RB reflectors of SEG * R doubles per LDS block
   const int per32 = (int)ndmps::ceil_div(n_max, 32), per64 = (int)ndmps::ceil_div(n_max, 64);
-  if (per32 <= 4)
-    hipLaunchKernelGGL((trd_back_kernel<32, 4>), dim3(ndmps::ceil_div(kk, 8), B), dim3(256), 0, s, desc, w);
-  else if (per32 <= 8)
-    hipLaunchKernelGGL((trd_back_kernel<32, 8>), dim3(ndmps::ceil_div(kk, 8), B), dim3(256), 0, s, desc, w);
-  else if (per32 <= 16)
-    hipLaunchKernelGGL((trd_back_kernel<32, 16>), dim3(ndmps::ceil_div(kk, 8), B), dim3(256), 0, s, desc, w);
-  else if (per32 <= 32)
-    hipLaunchKernelGGL((trd_back_kernel<32, 32>), dim3(ndmps::ceil_div(kk, 8), B), dim3(256), 0, s, desc, w);
-  else if (per64 <= 32)
-    hipLaunchKernelGGL((trd_back_kernel<64, 32>), dim3(ndmps::ceil_div(kk, 4), B), dim3(256), 0, s, desc, w);
-  else
-    hipLaunchKernelGGL((trd_back_kernel<64, 64>), dim3(ndmps::ceil_div(kk, 4), B), dim3(256), 0, s, desc, w);
+#define NDMPS_BACK(SEG, R, RB)                                                                          \
+  hipLaunchKernelGGL((trd_back_kernel<SEG, R, RB>), dim3(ndmps::ceil_div(kk, 256 / SEG), B), dim3(256), \
+                     (size_t)2 * RB * SEG * R * sizeof(double), s, desc, w)
+  if (per32 <= 4) NDMPS_BACK(32, 4, 8);
+  else if (per32 <= 8) NDMPS_BACK(32, 8, 8);
+  else if (per32 <= 16) NDMPS_BACK(32, 16, 8);
+  else if (per32 <= 32) NDMPS_BACK(32, 32, 4);
+  else if (per64 <= 32) NDMPS_BACK(64, 32, 2);
+  else NDMPS_BACK(64, 64, 1);
+#undef NDMPS_BACK
   NDMPS_LAUNCH_CHECK();
   if (h_status) {
     std::vector<TrdDesc> host(batch);

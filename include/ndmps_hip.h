@@ -168,6 +168,9 @@ int ndmps_syevj_batched_vectors_f64(int batch, double* d_G, int64_t stride_G, co
 int64_t ndmps_syevd_topk_max_n(void);
 int64_t ndmps_syevd_topk_max_k(void);
 int64_t ndmps_syevd_topk_workspace_bytes(int64_t n_max, int batch, int64_t k_max);
+/* byte offset, inside the workspace, of 16 int64 wall-clock marks (100 MHz) per matrix left by the vectors
+ * phase (profiling aid, tools/trd_probe.py) */
+int64_t ndmps_syevd_topk_stamps_offset(int64_t n_max, int batch, int64_t k_max);
 int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t stride_G, const int64_t* h_n,
                                 double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
                                 int64_t k_max, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);

@@ -60,6 +60,10 @@ def trd_all():
 
 tv = timed(trd_values)
 ta = timed(trd_all)
+off = lib.ndmps_syevd_topk_stamps_offset(n, B, k)
+st = ws[off:off + 16 * 8].view(torch.int64).cpu().numpy()
+names = ["factor+fwd", "solves", "gram1", "chol1", "trsm1", "gram2", "chol2", "trsm2"]
+print("invit phases (us, matrix 0): " + ", ".join(f"{nm} {(st[i + 1] - st[i]) / 100:.1f}" for i, nm in enumerate(names)))
 w_trd = w.clone()
 v_trd = v.clone()
 nbj = lib.ndmps_syevj_batched_workspace_bytes(n, B)
