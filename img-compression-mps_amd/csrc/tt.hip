@@ -101,6 +101,110 @@ __global__ void __launch_bounds__(256) sqrt_clamp_kernel(const double* __restric
     s[i] = sqrt(fmax(w[i], 0.0));
 }
 
+// ------------------------------------------------------------ merged trailing sites (bond-capped sweep)
+// While a bond is exact (the product N_{i+1} of the site dims to its right does not exceed the cap) site i's
+// unfolding is the RAW unfolding A_i (M_i x N_i) times a block-diagonal basis:  A_i (I_{d_i} (x) W_{i+1}),
+// W_{i+1} (N_{i+1} x k_{i+1}) the accumulated right bases.  Its Gram matrix is therefore a congruence of the
+// raw one, and the raw Gram matrices of all those sites are block sums of the largest:
+//     G_i = B^T Graw_i B,  B = I (x) W_{i+1},   Graw_{i+1} = sum of the d_i diagonal blocks of Graw_i.
+// One Gram pass over the raw tensor (order N_{i0}) thus serves every site i >= i0, and one projection
+// A_{i0} W_{i0} replaces the per-site projections: the tensor is read twice instead of once per Gram and
+// once per projection of every site, and the cores are the same SVD cores (same arithmetic, fewer roundings).
+struct MergeRanks {  // per-volume ranks of one launch (kernel argument)
+  int k_right[64];   // k_{i+1}
+  int k_here[64];    // k_i (w_update only)
+};
+
+// T (N_i x n_i) = Graw_i B:  T[r][(b, q)] = sum_c' Graw_i[r][b N' + c'] W[c'][q],
+// Graw_i[r][c] = sum_t Graw[(t N_i + r)][(t N_i + c)]  (t over the N_top / N_i diagonal blocks of the top Gram)
+__global__ void __launch_bounds__(256)
+merge_stage1_kernel(const double* __restrict__ Gtop, int64_t stride_top, int n_top, const double* __restrict__ W,
+                    int64_t stride_w, int ldw, double* __restrict__ T, int64_t stride_t, int n_i, int n_right,
+                    int d_i, MergeRanks rk) {
+  const int b = blockIdx.y;
+  const int k = rk.k_right[b];
+  const int cols = d_i * k;  // n_i of this volume
+  const double* G = Gtop + (int64_t)b * stride_top;
+  const double* Wb = W + (int64_t)b * stride_w;
+  double* Tb = T + (int64_t)b * stride_t;
+  const int reps = n_top / n_i;
+  const int64_t total = (int64_t)n_i * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int r = (int)(e / cols), col = (int)(e % cols);
+    const int bb = col / k, q = col % k;
+    double acc = 0.0;
+    for (int t = 0; t < reps; ++t) {
+      const double* grow = G + (int64_t)(t * n_i + r) * n_top + t * n_i + bb * n_right;
+      for (int c = 0; c < n_right; ++c) acc = fma(grow[c], Wb[(int64_t)c * ldw + q], acc);
+    }
+    Tb[e] = acc;
+  }
+}
+
+// G_i (n_i x n_i, ld n_i) = B^T T:  G[(a, p)][j] = sum_c' W[c'][p] T[(a N' + c')][j]
+__global__ void __launch_bounds__(256)
+merge_stage2_kernel(const double* __restrict__ T, int64_t stride_t, const double* __restrict__ W, int64_t stride_w,
+                    int ldw, double* __restrict__ Gout, int64_t stride_g, int n_right, int d_i, MergeRanks rk) {
+  const int b = blockIdx.y;
+  const int k = rk.k_right[b];
+  const int n = d_i * k;
+  const double* Tb = T + (int64_t)b * stride_t;
+  const double* Wb = W + (int64_t)b * stride_w;
+  double* Gb = Gout + (int64_t)b * stride_g;
+  const int64_t total = (int64_t)n * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int row = (int)(e / n), j = (int)(e % n);
+    const int a = row / k, pp = row % k;
+    double acc = 0.0;
+    for (int c = 0; c < n_right; ++c) acc = fma(Wb[(int64_t)c * ldw + pp], Tb[(int64_t)(a * n_right + c) * n + j], acc);
+    Gb[e] = acc;
+  }
+}
+
+// W_i (N_i x k_i, ld ldw) = B V_i:  W_i[(a, c')][p] = sum_q W_{i+1}[c'][q] V[(a k_{i+1} + q)][p]   (V: n_i x n_i, ld n_i)
+// optionally also as fp32 (ld = k_i, compact) for the projection GEMM
+__global__ void __launch_bounds__(256)
+merge_basis_kernel(const double* __restrict__ Wr, int64_t stride_w, int ldw, const double* __restrict__ V,
+                   int64_t stride_v, double* __restrict__ Wout, float* __restrict__ W32, int64_t stride_w32,
+                   int n_right, int d_i, MergeRanks rk) {
+  const int b = blockIdx.y;
+  const int kr = rk.k_right[b], kh = rk.k_here[b];
+  const int n = d_i * kr;
+  const double* Wb = Wr + (int64_t)b * stride_w;
+  const double* Vb = V + (int64_t)b * stride_v;
+  double* Ob = Wout + (int64_t)b * stride_w;
+  float* O32 = W32 ? W32 + (int64_t)b * stride_w32 : nullptr;
+  const int64_t total = (int64_t)d_i * n_right * kh;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int row = (int)(e / kh), pp = (int)(e % kh);
+    const int a = row / n_right, c = row % n_right;
+    double acc = 0.0;
+    for (int q = 0; q < kr; ++q) acc = fma(Wb[(int64_t)c * ldw + q], Vb[(int64_t)(a * kr + q) * n + pp], acc);
+    Ob[(int64_t)row * ldw + pp] = acc;
+    if (O32) O32[(int64_t)row * kh + pp] = (float)acc;
+  }
+}
+
+__global__ void merge_basis_init_kernel(double* __restrict__ W, int64_t stride_w) {
+  W[(int64_t)blockIdx.x * stride_w] = 1.0;  // W_L = [1]
+}
+
+constexpr int64_t kMergeMax = 512;  // largest raw Gram order of the merged sites
+
+// first site of the merged run, or L when nothing is merged (see the comment above)
+int merge_start(int L, const int64_t* dims, int64_t numel, int64_t max_bond) {
+  if (max_bond <= 0 || getenv("NDMPS_SWEEP_NO_MERGE")) return L;
+  int best = L;
+  int64_t right = 1;  // N_{i+1}
+  for (int i = L - 1; i >= 1; --i) {
+    const int64_t n_i = right * dims[i];
+    if (right > max_bond || n_i > kMergeMax || numel / n_i < n_i) break;
+    best = i;
+    right = n_i;
+  }
+  return best >= L - 1 ? L : best;  // a run of one site is the ordinary path
+}
+
 // keep s_k > cutoff * s_0 (at least one), at most max_bond
 int64_t kept_rank(const std::vector<double>& sigma, double cutoff, int64_t max_bond) {
   const int64_t n = (int64_t)sigma.size();
@@ -148,6 +252,9 @@ struct SweepLayout {
   int64_t small_max = 1;      // largest eigenproblem
   int64_t gram_ws = 0;        // largest Gram workspace
   int64_t wide_elems = 0;     // largest wide unfolding (m < n), elements
+  int merge_from = 0;         // first site of the merged trailing run (== L: none)
+  int64_t merge_n = 0;        // order of its raw Gram matrix
+  int64_t merge_w = 0;        // leading dimension of the accumulated bases
   int64_t workspace = 0;      // for the batch size it was computed for
 };
 
@@ -181,6 +288,13 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
       else out.wide_elems = std::max(out.wide_elems, m * n);
     }
   }
+  out.merge_from = merge_start(L, dims, out.numel, max_bond);
+  out.merge_n = out.merge_from < L ? right[out.merge_from] : 0;
+  out.merge_w = out.merge_from < L ? std::min(out.merge_n, max_bond) : 0;
+  if (out.merge_from < L) {
+    out.small_max = std::max(out.small_max, out.merge_n);
+    out.gram_ws = std::max(out.gram_ws, gram_ws_bound(out.merge_n));
+  }
   const int64_t sq = out.small_max * out.small_max;
   int64_t used = 0;
   used = arena_bytes(used, 4, (int64_t)batch * out.numel);              // second carry buffer per volume
@@ -192,6 +306,11 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
   used = arena_bytes(used, 1, out.gram_ws);                             // shared, stream-ordered
   used = arena_bytes(used, 8, (int64_t)batch * out.wide_elems);         // A64 per volume
   used = arena_bytes(used, 8, out.wide_elems);                          // U_k^T A64, shared
+  used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_n);      // raw Gram of the merged run
+  used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_n);      // T = Graw B
+  used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_w);      // accumulated basis W (ping)
+  used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_w);      // (pong)
+  used = arena_bytes(used, 4, (int64_t)batch * out.merge_n * out.merge_w);      // fp32 copy for the projection
   out.workspace = ndmps::round_up(used, 256) + 256;
   return NDMPS_OK;
 }
@@ -252,6 +371,13 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
   double* UtA = ar.take<double>(lay.wide_elems);
   NDMPS_REQUIRE(other && G && V && w && sig && ev_ws && gram_ws && A64 && UtA, "workspace carve failed");
 
+  double* Graw = ar.take<double>((int64_t)batch * lay.merge_n * lay.merge_n);
+  double* Tm = ar.take<double>((int64_t)batch * lay.merge_n * lay.merge_n);
+  double* Wm[2] = {ar.take<double>((int64_t)batch * lay.merge_n * lay.merge_w),
+                   ar.take<double>((int64_t)batch * lay.merge_n * lay.merge_w)};
+  float* W32 = ar.take<float>((int64_t)batch * lay.merge_n * lay.merge_w);
+  NDMPS_REQUIRE(Graw && Tm && Wm[0] && Wm[1] && W32, "workspace carve failed");
+
   std::vector<float*> cur(batch), nxt(batch);
   std::vector<int64_t> chi_r(batch, 1), cur_elems(batch, lay.numel), eig_n(batch), kept(batch);
   for (int b = 0; b < batch; ++b) {
@@ -264,7 +390,122 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
   std::vector<double> host_w((size_t)batch * lay.small_max);
   std::vector<int> eig_status;
 
-  for (int i = L - 1; i >= 1; --i) {
+  // One batched eigen-solve for site i on the matrices G[b] (order eig_n[b], ld eig_n[b]): eigenvalues to the
+  // host, rank decision per volume (kept[b]), then the kept eigenvectors in the columns of V[b].
+  auto solve_site = [&](int i) -> int {
+    int sweeps = 0;
+    int64_t site_n = 0;
+    for (int b = 0; b < batch; ++b) site_n = std::max(site_n, eig_n[b]);
+    const bool topk = use_topk(site_n, max_bond);
+    const int64_t k_cap = std::min<int64_t>(max_bond, site_n);
+    if (topk)
+      NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
+                                            ev_ws_bytes, s));
+    else
+      NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(),
+                                               ev_ws, ev_ws_bytes, &sweeps, s));
+    NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
+                                   hipMemcpyDeviceToHost, s));
+    NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+    for (int b = 0; b < batch; ++b) {
+      const int64_t small = eig_n[b];
+      std::vector<double> sv(host_w.begin() + (int64_t)b * lay.small_max,
+                             host_w.begin() + (int64_t)b * lay.small_max + small);
+      for (auto& x : sv) x = sqrt(std::max(x, 0.0));
+      kept[b] = kept_rank(sv, cutoff, max_bond);
+      if (h_spectra && h_spec_offsets) {
+        // the layout reserves min(m, d_i max_bond_{i+1}) values for the bond; a merged site may be larger
+        const int64_t room = h_spec_offsets[i + 1] - h_spec_offsets[i];
+        memcpy(h_spectra + (int64_t)b * spec_total + h_spec_offsets[i], sv.data(),
+               std::min(small, room) * sizeof(double));
+      }
+    }
+    if (topk) {
+      eig_status.assign(batch, 0);
+      NDMPS_TRY(ndmps_syevd_topk_vectors_f64(batch, eig_n.data(), kept.data(), k_cap, ev_ws, ev_ws_bytes,
+                                             eig_status.data(), s));
+      for (int b = 0; b < batch; ++b)
+        if (eig_status[b] != 0) {
+          ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", i, b);
+          return NDMPS_ENOCONV;
+        }
+    } else {
+      NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(),
+                                                ev_ws, ev_ws_bytes, s));
+    }
+    return NDMPS_OK;
+  };
+
+  int i_start = L - 1;
+  if (lay.merge_from < L) {
+    // ---- merged trailing run: sites merge_from .. L-1 from ONE Gram pass and ONE projection pass
+    const int i0 = lay.merge_from;
+    const int64_t n0 = lay.merge_n, ldw = lay.merge_w, m0 = lay.numel / n0;
+    const int64_t stride_top = n0 * n0, stride_w = n0 * ldw;
+    for (int b = 0; b < batch; ++b)
+      NDMPS_TRY(ndmps_gram_f32(cur[b], m0, n0, n0, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
+    hipLaunchKernelGGL(merge_basis_init_kernel, dim3(batch), dim3(1), 0, s, Wm[0], stride_w);
+    NDMPS_LAUNCH_CHECK();
+    int wcur = 0;
+    int64_t n_right = 1;  // N_{i+1}
+    for (int i = L - 1; i >= i0; --i) {
+      const int64_t d_i = h_dims[i], n_i = n_right * d_i;
+      for (int base = 0; base < batch; base += 64) {
+        const int count = std::min(64, batch - base);
+        MergeRanks rk;
+        int64_t biggest = 1;
+        for (int t = 0; t < count; ++t) {
+          rk.k_right[t] = (int)chi_r[base + t];
+          rk.k_here[t] = 0;
+          eig_n[base + t] = d_i * chi_r[base + t];
+          biggest = std::max(biggest, eig_n[base + t]);
+        }
+        const int g1 = (int)std::min<int64_t>(ceil_div(n_i * biggest, 256), 1024);
+        const int g2 = (int)std::min<int64_t>(ceil_div(biggest * biggest, 256), 1024);
+        hipLaunchKernelGGL(merge_stage1_kernel, dim3(g1, count), dim3(256), 0, s, Graw + base * stride_top, stride_top,
+                           (int)n0, Wm[wcur] + base * stride_w, stride_w, (int)ldw, Tm + base * stride_top, stride_top,
+                           (int)n_i, (int)n_right, (int)d_i, rk);
+        hipLaunchKernelGGL(merge_stage2_kernel, dim3(g2, count), dim3(256), 0, s, Tm + base * stride_top, stride_top,
+                           Wm[wcur] + base * stride_w, stride_w, (int)ldw, G + base * sq, sq, (int)n_right, (int)d_i, rk);
+      }
+      NDMPS_LAUNCH_CHECK();
+      NDMPS_TRY(solve_site(i));
+      for (int base = 0; base < batch; base += 64) {
+        const int count = std::min(64, batch - base);
+        MergeRanks rk;
+        int64_t biggest = 1;
+        for (int t = 0; t < count; ++t) {
+          rk.k_right[t] = (int)chi_r[base + t];
+          rk.k_here[t] = (int)kept[base + t];
+          biggest = std::max(biggest, kept[base + t]);
+        }
+        const int g3 = (int)std::min<int64_t>(ceil_div(n_i * biggest, 256), 1024);
+        hipLaunchKernelGGL(merge_basis_kernel, dim3(g3, count), dim3(256), 0, s, Wm[wcur] + base * stride_w, stride_w,
+                           (int)ldw, V + base * sq, sq, Wm[wcur ^ 1] + base * stride_w,
+                           i == i0 ? W32 + base * stride_w : nullptr, stride_w, (int)n_right, (int)d_i, rk);
+      }
+      NDMPS_LAUNCH_CHECK();
+      for (int b = 0; b < batch; ++b) {
+        const int64_t n = eig_n[b], k = kept[b];
+        hipLaunchKernelGGL(core_from_vectors_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, V + (int64_t)b * sq, n, k,
+                           h_cores[b] + h_core_offsets[i]);
+        chi_r[b] = k;
+        h_bonds_out[(int64_t)b * (L + 1) + i] = k;
+      }
+      NDMPS_LAUNCH_CHECK();
+      wcur ^= 1;
+      n_right = n_i;
+    }
+    for (int b = 0; b < batch; ++b) {  // carry = A_raw W (m0 x k)
+      const int64_t k = chi_r[b];
+      NDMPS_TRY(ndmps_sgemm(0, 0, m0, k, n0, cur[b], n0, W32 + (int64_t)b * stride_w, k, nxt[b], k, s));
+      std::swap(cur[b], nxt[b]);
+      cur_elems[b] = m0 * k;
+    }
+    i_start = i0 - 1;
+  }
+
+  for (int i = i_start; i >= 1; --i) {
     // ---- small-side Gram matrices
     int64_t m = 0;
     for (int b = 0; b < batch; ++b) {
@@ -284,44 +525,7 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
         NDMPS_TRY(ndmps_dgemm(0, 1, m, m, n, Ab, n, Ab, n, Gb, m, s));
       }
     }
-    // ---- one batched eigen-solve for the site
-    int sweeps = 0;
-    int64_t site_n = 0;
-    for (int b = 0; b < batch; ++b) site_n = std::max(site_n, eig_n[b]);
-    const bool topk = use_topk(site_n, max_bond);
-    const int64_t k_cap = std::min<int64_t>(max_bond, site_n);
-    if (topk)
-      NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
-                                            ev_ws_bytes, s));
-    else
-      NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(),
-                                               ev_ws, ev_ws_bytes, &sweeps, s));
-    NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
-                                   hipMemcpyDeviceToHost, s));
-    NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-    // ---- rank decision per volume, then only the kept eigenvectors
-    for (int b = 0; b < batch; ++b) {
-      const int64_t small = eig_n[b];
-      std::vector<double> sv(host_w.begin() + (int64_t)b * lay.small_max,
-                             host_w.begin() + (int64_t)b * lay.small_max + small);
-      for (auto& x : sv) x = sqrt(std::max(x, 0.0));
-      kept[b] = kept_rank(sv, cutoff, max_bond);
-      if (h_spectra && h_spec_offsets)
-        memcpy(h_spectra + (int64_t)b * spec_total + h_spec_offsets[i], sv.data(), small * sizeof(double));
-    }
-    if (topk) {
-      eig_status.assign(batch, 0);
-      NDMPS_TRY(ndmps_syevd_topk_vectors_f64(batch, eig_n.data(), kept.data(), k_cap, ev_ws, ev_ws_bytes,
-                                             eig_status.data(), s));
-      for (int b = 0; b < batch; ++b)
-        if (eig_status[b] != 0) {
-          ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", i, b);
-          return NDMPS_ENOCONV;
-        }
-    } else {
-      NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(),
-                                                ev_ws, ev_ws_bytes, s));
-    }
+    NDMPS_TRY(solve_site(i));
     // ---- core and carried matrix per volume
     for (int b = 0; b < batch; ++b) {
       const int64_t n = h_dims[i] * chi_r[b];
@@ -478,14 +682,47 @@ extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int
 }
 
 // =================================================================== chain contraction
+// Left->right like quimb's structured contraction (core/ndmps.py:140), with the tail pre-contracted: the
+// sites j0 .. L-1 whose physical dims multiply to N_{j0} <= 4096 are first contracted among themselves,
+// right to left, into R (k_{j0} x N_{j0}) -- GEMMs on matrices of at most a few MB -- so the tensor itself is
+// written ONCE, by the last GEMM  Left (M_{j0} x k_{j0}) R.  The cumulative chain alone would write an
+// N-element intermediate per trailing site and read it back (2 x 64 MB per site at 256^3 for multiplications
+// by 64 x 64 and 8 x 8 matrices).  Same fp32 products, different association.
+namespace {
+constexpr int64_t kChainTailMax = 4096;
+
+struct ChainPlan {
+  int j0 = 0;            // first site of the pre-contracted tail (== L: no tail, j0 == 0 never)
+  int64_t left_elems = 0, tail_elems = 0;
+};
+
+ChainPlan chain_plan(int L, const int64_t* dims, const int64_t* bonds) {
+  ChainPlan p;
+  p.j0 = L;
+  int64_t right = 1;
+  for (int i = L - 1; i >= 1; --i) {
+    if (right * dims[i] > kChainTailMax) break;
+    right *= dims[i];
+    p.j0 = i;
+  }
+  int64_t rows = 1;
+  for (int i = 0; i < p.j0 && i < L; ++i) {
+    rows *= dims[i];
+    p.left_elems = std::max(p.left_elems, rows * bonds[i + 1]);
+  }
+  int64_t n = 1;
+  for (int i = L - 1; i >= p.j0; --i) {
+    n *= dims[i];
+    p.tail_elems = std::max(p.tail_elems, bonds[i] * n);
+  }
+  return p;
+}
+}  // namespace
+
 extern "C" int64_t ndmps_chain_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds) {
   if (L < 1 || !h_dims || !h_bonds) return 0;
-  int64_t rows = 1, biggest = 1;
-  for (int i = 0; i < L; ++i) {
-    rows *= h_dims[i];
-    biggest = std::max(biggest, rows * h_bonds[i + 1]);
-  }
-  return biggest * (int64_t)sizeof(float) + 512;
+  const ChainPlan p = chain_plan(L, h_dims, h_bonds);
+  return (ndmps::round_up(p.left_elems, 64) + 2 * ndmps::round_up(p.tail_elems, 64)) * (int64_t)sizeof(float) + 512;
 }
 
 extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int64_t* h_bonds,
@@ -493,10 +730,11 @@ extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int6
                                         int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(L >= 1 && h_dims && h_bonds && h_cores && d_dense, "bad chain argument");
   NDMPS_REQUIRE(h_bonds[0] == 1 && h_bonds[L] == 1, "open boundary bonds must be 1");
+  int64_t numel = 1;
   {
-    // the intermediates ping-pong between d_ws and d_dense (N = prod(dims) elements): every bond must be
-    // at most the product of the site dims on either side of it, as any MPS of a dense tensor has
-    int64_t numel = 1, left = 1;
+    // every intermediate lands in d_ws or d_dense (N = prod(dims) elements): every bond must be at most the
+    // product of the site dims on either side of it, as any MPS of a dense tensor has
+    int64_t left = 1;
     for (int i = 0; i < L; ++i) {
       NDMPS_REQUIRE(h_dims[i] >= 1 && h_cores[i], "dims[%d] must be positive and core %d non-NULL", i, i);
       numel *= h_dims[i];
@@ -514,19 +752,47 @@ extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int6
     return NDMPS_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  float* bufs[2] = {d_dense, (float*)d_ws};
-  // L-1 GEMMs; arrange the ping-pong so the last one lands in d_dense
-  int dst = (L - 1) % 2 == 0 ? 0 : 1;  // buffer that receives the copy of core 0
+  if (L == 1) {
+    NDMPS_CHECK_HIP(hipMemcpyAsync(d_dense, h_cores[0], numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return NDMPS_OK;
+  }
+  const ChainPlan p = chain_plan(L, h_dims, h_bonds);
+  float* ws_left = (float*)d_ws;
+  float* ws_tail[2] = {ws_left + ndmps::round_up(p.left_elems, 64),
+                       ws_left + ndmps::round_up(p.left_elems, 64) + ndmps::round_up(p.tail_elems, 64)};
+  const int j0 = p.j0;
+  // ---- tail, right to left: R_i (k_i x N_i) = [core_i as (k_i d_i) x k_{i+1}] R_{i+1}
+  const float* R = nullptr;
+  int64_t n_tail = 1;
+  if (j0 < L) {
+    R = h_cores[L - 1];
+    n_tail = h_dims[L - 1];
+    int t = 0;
+    for (int i = L - 2; i >= j0; --i) {
+      NDMPS_TRY(ndmps_sgemm(0, 0, h_bonds[i] * h_dims[i], n_tail, h_bonds[i + 1], h_cores[i], h_bonds[i + 1], R, n_tail,
+                            ws_tail[t], n_tail, s));
+      R = ws_tail[t];
+      t ^= 1;
+      n_tail *= h_dims[i];
+    }
+  }
+  // ---- left part, cumulative: Left_i (rows_i x k_{i+1}); the last product of the whole chain writes d_dense,
+  //      the one before it must therefore land in the workspace
+  const int last_left = j0 < L ? j0 - 1 : L - 1;  // index of the last cumulative GEMM (site index), 0: none
+  const float* left = h_cores[0];
   int64_t rows = h_dims[0];
-  NDMPS_CHECK_HIP(hipMemcpyAsync(bufs[dst], h_cores[0], rows * h_bonds[1] * sizeof(float),
-                                 hipMemcpyDeviceToDevice, s));
-  for (int i = 1; i < L; ++i) {
+  for (int i = 1; i <= last_left; ++i) {
     const int64_t chi = h_bonds[i], cols = h_dims[i] * h_bonds[i + 1];
-    NDMPS_TRY(ndmps_sgemm(0, 0, rows, cols, chi, bufs[dst], chi, h_cores[i], cols, bufs[dst ^ 1], cols, s));
-    dst ^= 1;
+    // products remaining after this one (cumulative ones + the final Left R)
+    const int remaining = (last_left - i) + (j0 < L ? 1 : 0);
+    float* out = remaining % 2 == 0 ? d_dense : ws_left;
+    NDMPS_TRY(ndmps_sgemm(0, 0, rows, cols, chi, left, chi, h_cores[i], cols, out, cols, s));
+    left = out;
     rows *= h_dims[i];
   }
-  NDMPS_REQUIRE(dst == 0, "internal: chain result landed in the wrong buffer");
+  if (j0 < L)
+    NDMPS_TRY(ndmps_sgemm(0, 0, rows, n_tail, h_bonds[j0], left, h_bonds[j0], R, n_tail, d_dense, n_tail, s));
+  NDMPS_REQUIRE(j0 < L || left == d_dense, "internal: chain result landed in the wrong buffer");
   return NDMPS_OK;
 }
 
