@@ -36,7 +36,6 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTail = 128;        // trailing order finished in LDS by one workgroup
 constexpr int kTailLd = 132;      // LDS row stride of the tail matrix (ld = 4 mod 32: conflict-free row walks)
-constexpr int kColsPerWg = 32;    // columns of one workgroup of the column kernel
 constexpr int kMaxK = 128;        // largest number of eigenvectors (Cholesky factor lives in LDS)
 constexpr int kMaxN = 4096;       // three n-vectors of the column kernel live in LDS
 
@@ -141,19 +140,26 @@ __global__ void __launch_bounds__(256) trd_load_kernel(const TrdDesc* __restrict
 // workgroup's whole share of the trailing matrix (up to 32 tiles of 16 bytes per lane = 512 rows; more rows
 // stream afterwards), the three n-vectors of the prologue and the five scalars it broadcasts.  The
 // prologue's arithmetic then runs under the flight time of the matrix tiles.
-//   NR: n-vector elements per thread (n <= 256 NR).
 struct __attribute__((aligned(16))) RowVec {  // per-row operands of the body, one 32-byte LDS record
   double vp, wp, vj, pad;
 };
 
-template <int NR>
+//   NR: n-vector elements per thread (n <= 256 NR).  CW: columns per workgroup, 32 or 8: a workgroup draws
+//   ~33 GB/s from the Infinity Cache whatever it does, so few matrices are cut into many narrow column
+//   blocks (a 512-row launch of one matrix: 12.6 us with 16 workgroups of 32 columns) and many matrices into
+//   wide ones (the redundant prologue is paid per workgroup).
+template <int NR, int CW>
 __global__ void __launch_bounds__(256)
 trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
+  constexpr int LPR = CW / 2;        // lanes per row (16 bytes each)
+  constexpr int RPW = 64 / LPR;      // rows per wave instruction
+  constexpr int RPI = 4 * RPW;       // rows per workgroup iteration
+  constexpr int PRE = 512 / RPI;     // tiles prefetched per lane: 512 rows
   const TrdDesc& d = desc[blockIdx.y];
   const int n = d.n;
   if (j >= n - kTail) return;              // this matrix is (or will be) finished by the tail kernel
-  const int c0 = blockIdx.x * kColsPerWg;
-  if (c0 >= n || c0 + kColsPerWg <= j + 1) return;  // columns <= j are finished
+  const int c0 = blockIdx.x * CW;
+  if (c0 >= n || c0 + CW <= j + 1) return;  // columns <= j are finished
   const int lda = w.lda;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b = blockIdx.y;
@@ -163,18 +169,17 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   RowVec* rv = reinterpret_cast<RowVec*>(lds);  // [n]
   __shared__ double red_a[4], red_b[4];
-  __shared__ double part[4][kColsPerWg];
+  __shared__ double part[4][CW];
 
   // ---- every load whose address is known: matrix tiles first (the longest flight)
-  constexpr int PRE = 32;
-  const int q = lane >> 4, p = lane & 15;
+  const int q = lane / LPR, p = lane % LPR;
   const int c = c0 + 2 * p;
   const bool col_ok = c < lda;  // lda is even: c + 1 < lda too; the padding column holds zeros
-  const int first = j + 1 + 4 * wave + q;
+  const int first = j + 1 + RPW * wave + q;
   double2 a[PRE];
 #pragma unroll
   for (int u = 0; u < PRE; ++u) {
-    const int i = first + 16 * u;
+    const int i = first + RPI * u;
     a[u] = (i < n && col_ok) ? *reinterpret_cast<const double2*>(A + (int64_t)i * lda + c) : make_double2(0.0, 0.0);
   }
   const double* rowj = A + (int64_t)j * lda;
@@ -232,7 +237,7 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
   const double alpha = r_j1 - ((taup * y_j1 - al * v_j1) + wpj * v_j1);
   double beta, tau, scale;
   householder(alpha, sigma, beta, tau, scale);
-  const bool writer = (int)blockIdx.x == (j + 1) / kColsPerWg;
+  const bool writer = (int)blockIdx.x == (j + 1) / CW;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int i = tid + 256 * r;
@@ -265,7 +270,7 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
   double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
   for (int u = 0; u < PRE; ++u) {
-    const int i = first + 16 * u;
+    const int i = first + RPI * u;
     if (i < n && col_ok) {
       const RowVec rec = rv[i];
       if (j >= 1) {
@@ -279,16 +284,16 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
   }
   // rows beyond the prefetched 512 (orders above 512 + j)
   constexpr int U = 8;
-  for (int i0 = first + 16 * PRE; i0 < n; i0 += 16 * U) {
+  for (int i0 = first + RPI * PRE; i0 < n; i0 += RPI * U) {
     double2 t[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = i0 + 16 * u;
+      const int i = i0 + RPI * u;
       t[u] = (i < n && col_ok) ? *reinterpret_cast<const double2*>(A + (int64_t)i * lda + c) : make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = i0 + 16 * u;
+      const int i = i0 + RPI * u;
       if (i < n && col_ok) {
         const RowVec rec = rv[i];
         if (j >= 1) {
@@ -302,16 +307,17 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
     }
   }
   // ---- epilogue: rows -> one value per column, fixed order
-  acc0 += __shfl_xor(acc0, 16, 64);
-  acc0 += __shfl_xor(acc0, 32, 64);
-  acc1 += __shfl_xor(acc1, 16, 64);
-  acc1 += __shfl_xor(acc1, 32, 64);
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc0 += __shfl_xor(acc0, off, 64);
+    acc1 += __shfl_xor(acc1, off, 64);
+  }
   if (q == 0) {
     part[wave][2 * p] = acc0;
     part[wave][2 * p + 1] = acc1;
   }
   __syncthreads();
-  if (tid < kColsPerWg && c0 + tid < lda)
+  if (tid < CW && c0 + tid < lda)
     ybuf[(j & 1) * lda + c0 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
@@ -1017,7 +1023,9 @@ int trd_opt_in() {
   if (dev < 0 || dev >= 64 || done[dev]) return NDMPS_OK;
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_tail_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLds));
-  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_column_kernel<16>),
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_column_kernel<16, 32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMaxN * (int)sizeof(RowVec)));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_column_kernel<16, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxN * (int)sizeof(RowVec)));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_invit_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
@@ -1090,12 +1098,21 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
   const unsigned B = (unsigned)batch;
   const int load_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * l.lda, 256), 512);
   hipLaunchKernelGGL(trd_load_kernel, dim3(load_grid, B), dim3(256), 0, s, desc, w);
-  const int W = (int)ndmps::ceil_div(n_max, kColsPerWg);
+  // narrow column blocks while the grid stays below ~2 workgroups per CU (see trd_column_kernel)
+  const bool narrow = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= 2 * ndmps::kNumCU && !getenv("NDMPS_TRD_WIDE");
+  const int W = (int)ndmps::ceil_div(n_max, narrow ? 8 : 32);
   const size_t col_lds = (size_t)n_max * sizeof(RowVec);
-  auto column = n_max <= 512    ? trd_column_kernel<2>
-                : n_max <= 1024 ? trd_column_kernel<4>
-                : n_max <= 2048 ? trd_column_kernel<8>
-                                : trd_column_kernel<16>;
+  void (*column)(const TrdDesc*, TrdWork, int);
+  if (narrow)
+    column = n_max <= 512    ? trd_column_kernel<2, 8>
+             : n_max <= 1024 ? trd_column_kernel<4, 8>
+             : n_max <= 2048 ? trd_column_kernel<8, 8>
+                             : trd_column_kernel<16, 8>;
+  else
+    column = n_max <= 512    ? trd_column_kernel<2, 32>
+             : n_max <= 1024 ? trd_column_kernel<4, 32>
+             : n_max <= 2048 ? trd_column_kernel<8, 32>
+                             : trd_column_kernel<16, 32>;
   for (int j = 0; j < n_max - kTail; ++j) hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
   hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
   const int kk = (int)std::min(k_max, n_max);
