@@ -50,7 +50,7 @@ def dumps(obj, dtype=np.uint16) -> bytes:
     members, bounds = [], []
     if name == "float32":
         for c in cores:
-            members.append(_gzip_member(c.cpu().numpy().tobytes()))
+            members.append(_gzip_member(c.float().cpu().numpy().tobytes()))
             bounds.append([0.0, 0.0])
     else:
         # the (min, max) scale_to_dtype derives from the data is what scale_back must be given

@@ -54,7 +54,7 @@ class DeviceCore:
         return self.tensor.shape[0]
 
     def __array__(self, dtype=None, copy=None):
-        arr = self.tensor.detach().cpu().numpy()
+        arr = self.tensor.detach().float().cpu().numpy()  # bf16 cores read as fp32 (NumPy has no bf16)
         return arr.astype(dtype) if dtype is not None else arr
 
     def numpy(self):
@@ -203,6 +203,16 @@ class DeviceMPS:
     def _core_ptrs(self):
         return (C.c_void_p * len(self.cores))(*[c.data_ptr() for c in self.cores])
 
+    def _f32_ptrs(self):
+        """(keep-alive list, pointer array) of the cores as fp32 (bf16 cores are upcast: a few MB at most)."""
+        torch = _torch()
+        keep = [c if c.dtype == torch.float32 else c.to(torch.float32) for c in self.cores]
+        return keep, (C.c_void_p * len(keep))(*[c.data_ptr() for c in keep])
+
+    @property
+    def dtype(self):
+        return self.cores[0].dtype
+
     def __matmul__(self, other):
         """Unconjugated overlap <self|other> (core/ndmps.py:76,86), fp64 transfer matrices."""
         torch = _torch()
@@ -215,30 +225,36 @@ class DeviceMPS:
         nbytes = lib.ndmps_overlap_workspace_bytes(L, dims, ba, bb)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         out = C.c_double()
-        _lib.check(lib.ndmps_overlap_f32(L, dims, ba, self._core_ptrs(), bb, other._core_ptrs(),
-                                         C.byref(out), ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        keep_a, pa = self._f32_ptrs()
+        keep_b, pb = other._f32_ptrs()
+        _lib.check(lib.ndmps_overlap_f32(L, dims, ba, pa, bb, pb, C.byref(out), ws.data_ptr(), nbytes,
+                                         _lib.stream_ptr()))
+        del keep_a, keep_b
         return float(out.value)
 
     def to_dense(self, out=None):
-        """Left->right chain contraction (core/ndmps.py:140); returns N fp32 in site order."""
+        """Left->right chain contraction (core/ndmps.py:140); returns N elements in site order, in the
+        storage type of the cores (fp32, or bf16 on the bf16 MFMA)."""
         torch = _torch()
         lib = _lib.load()
         L = len(self.cores)
         dims, bonds = _lib.i64_array(self.dims), _lib.i64_array(self.bonds)
         numel = int(np.prod(self.dims, dtype=np.int64))
         if out is None:
-            out = torch.empty(numel, dtype=torch.float32, device=self.device)
+            out = torch.empty(numel, dtype=self.dtype, device=self.device)
         nbytes = lib.ndmps_chain_workspace_bytes(L, dims, bonds)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        _lib.check(lib.ndmps_chain_contract_f32(L, dims, bonds, self._core_ptrs(), out.data_ptr(),
-                                                ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        fn = lib.ndmps_chain_contract_bf16 if self.dtype == torch.bfloat16 else lib.ndmps_chain_contract_f32
+        _lib.check(fn(L, dims, bonds, self._core_ptrs(), out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr()))
         return out
 
     def compress_bond_(self, i, cutoff, max_bond=None):
-        """tensor_compress_bond on bond (i-1, i) (core/ndmps.py:104-106); returns the spectrum."""
+        """tensor_compress_bond on bond (i-1, i) (core/ndmps.py:104-106); returns the spectrum.  bf16 cores
+        are truncated in fp32 and stored back as bf16."""
         torch = _torch()
         lib = _lib.load()
-        t1, t2 = self.cores[i - 1], self.cores[i]
+        store = self.dtype
+        t1, t2 = self.cores[i - 1].to(torch.float32), self.cores[i].to(torch.float32)
         chi_l, d1, chi = (int(v) for v in t1.shape)
         _, d2, chi_r = (int(v) for v in t2.shape)
         nbytes = lib.ndmps_compress_bond_workspace_bytes(chi_l, d1, chi, d2, chi_r)
@@ -252,6 +268,6 @@ class DeviceMPS:
             int(max_bond) if max_bond else 0, new1.data_ptr(), new2.data_ptr(), C.byref(k), spec,
             ws.data_ptr(), nbytes, _lib.stream_ptr()))
         k = int(k.value)
-        self.cores[i - 1] = new1[: chi_l * d1 * k].view(chi_l, d1, k).clone()
-        self.cores[i] = new2[: k * d2 * chi_r].view(k, d2, chi_r).clone()
+        self.cores[i - 1] = new1[: chi_l * d1 * k].view(chi_l, d1, k).to(store, copy=True)
+        self.cores[i] = new2[: k * d2 * chi_r].view(k, d2, chi_r).to(store, copy=True)
         return np.array(spec[:], dtype=np.float64)

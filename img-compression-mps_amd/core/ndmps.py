@@ -171,7 +171,7 @@ class NDMPS:
     # ---------------------------------------------------------------------- encode
     @classmethod
     def from_tensor(cls, tensor, norm: bool = False, mode: str = "Std", max_bond=None,
-                    cutoff: float = 1e-10, device=None) -> "NDMPS":
+                    cutoff: float = 1e-10, device=None, dtype=None) -> "NDMPS":
         """
         Create an NDMPS instance from a tensor with encoding and optional normalization.
 
@@ -180,18 +180,27 @@ class NDMPS:
         mode : "Std" for raw encoding or "DCT" for last-axis DCT preprocessing.
         max_bond : optional bond cap chi applied during the sweep (None = exact sweep).
         cutoff : relative singular-value cutoff of the sweep (quimb from_dense default).
+        dtype : storage type in HBM, ``torch.float32`` (default) or ``torch.bfloat16`` (see from_tensors).
         """
         return cls.from_tensors([tensor], norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff,
-                                device=device)[0]
+                                device=device, dtype=dtype)[0]
 
     @classmethod
     def from_tensors(cls, tensors, norm: bool = False, mode: str = "Std", max_bond=None,
-                     cutoff: float = 1e-10, device=None):
+                     cutoff: float = 1e-10, device=None, dtype=None):
         """
         Encode a list of independent tensors OF THE SAME SHAPE in one batched pass (what the
         reference does with a Python loop, evaluation/benchmark.py:73-76).  The volumes go through
         the sites in lockstep, so each site's eigenproblems are solved by one batched launch
-        sequence; results are identical to calling ``from_tensor`` on each.
+        sequence; results equal those of ``from_tensor`` on each up to the rounding of the fp64
+        eigen-solver (its summation order depends on how many matrices are in flight).
+
+        ``dtype=torch.bfloat16`` selects bf16 STORAGE (the reference fixes float64 at ndmps.py:56;
+        BASELINE config 5 asks for bf16): the volume is read as bf16 (2 bytes per voxel, no fp32 copy),
+        the site-order tensor, the carried matrices of the sweep and the cores are bf16 in HBM, products
+        run on the bf16 MFMA with fp32 accumulation, Gram matrices and eigen-decompositions stay fp64.
+        ``to_tensor`` then contracts in bf16 as well.  Results carry bf16 rounding (2^-9 relative per
+        stored value).
         """
         torch = _torch()
         _lib.require_device()
@@ -205,15 +214,19 @@ class NDMPS:
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
+        store = torch.float32 if dtype is None else dtype
+        if store not in (torch.float32, torch.bfloat16):
+            raise ValueError("storage dtype must be torch.float32 or torch.bfloat16")
+        bf16 = store == torch.bfloat16
+        esize = 2 if bf16 else 4
         xs = []
         for tensor in tensors:
             if isinstance(tensor, torch.Tensor):
                 if tensor.dim() == 0:
                     raise ValueError("Shape cannot be empty.")
-                # bf16 / fp16 volumes stay 2 bytes per voxel in HBM until here; arithmetic is fp32
                 # the volume is only written to when it is normalised in place: copy then, otherwise
-                # an fp32 volume already resident on the device is read where it lies
-                x = tensor.detach().to(device=device, dtype=torch.float32).contiguous()
+                # a volume already resident on the device in the storage type is read where it lies
+                x = tensor.detach().to(device=device, dtype=store).contiguous()
                 if norm and x.data_ptr() == tensor.data_ptr():
                     x = x.clone()
             else:
@@ -222,7 +235,7 @@ class NDMPS:
                     raise ValueError("Shape cannot be empty.")
                 if arr.dtype.kind not in "fiub":
                     raise TypeError(f"unsupported tensor dtype {arr.dtype}")
-                x = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device)
+                x = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device).to(store)
             xs.append(x)
         shape = tuple(int(v) for v in xs[0].shape)
         if any(tuple(x.shape) != shape for x in xs):
@@ -234,6 +247,8 @@ class NDMPS:
             numel = plan.numel
             denses = []
             for x in xs:
+                if (norm or mode == "DCT") and bf16:
+                    x = x.to(torch.float32)  # the norm / DCT kernels are fp32; rounded back to bf16 below
                 if norm:
                     ws = torch.empty(lib.ndmps_reduce_workspace_bytes(), dtype=torch.uint8, device=device)
                     ss = C.c_double()
@@ -245,9 +260,10 @@ class NDMPS:
                     _lib.check(lib.ndmps_dct_last_f32(x.data_ptr(), y.data_ptr(), numel // n, n,
                                                       _dct_basis(n, device).data_ptr(), stream))
                     x = y
-                dense = torch.empty(numel, dtype=torch.float32, device=device)
+                x = x.to(store)
+                dense = torch.empty(numel, dtype=store, device=device)
                 with _span("encode_permute"):
-                    _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), 4, stream))
+                    _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), esize, stream))
                 denses.append(dense)
             del xs, x
 
@@ -262,7 +278,7 @@ class NDMPS:
             ws_bytes = lib.ndmps_tt_sweep_batched_workspace_bytes(batch, L, cdims, mb)
             if ws_bytes < 0:
                 _lib.check(_lib.EINVAL)
-            arenas = [torch.empty(int(core_off[L]), dtype=torch.float32, device=device) for _ in range(batch)]
+            arenas = [torch.empty(int(core_off[L]), dtype=store, device=device) for _ in range(batch)]
             ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=device)
             bonds = (C.c_int64 * (batch * (L + 1)))()
             spec_total = int(spec_off[L])
@@ -270,9 +286,9 @@ class NDMPS:
             dense_ptrs = (C.c_void_p * batch)(*[d.data_ptr() for d in denses])
             arena_ptrs = (C.c_void_p * batch)(*[a.data_ptr() for a in arenas])
             with _span("sweep"):
-                _lib.check(lib.ndmps_tt_sweep_batched_f32(batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs,
-                                                          core_off, bonds, spectra, spec_off, ws.data_ptr(),
-                                                          ws.numel(), stream))
+                sweep = lib.ndmps_tt_sweep_batched_bf16 if bf16 else lib.ndmps_tt_sweep_batched_f32
+                _lib.check(sweep(batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds, spectra,
+                                 spec_off, ws.data_ptr(), ws.numel(), stream))
             del ws, denses
             objs = []
             for b in range(batch):
@@ -385,11 +401,13 @@ class NDMPS:
             stream = _lib.stream_ptr()
             with _span("chain"):
                 dense = self.mps.to_dense()
-            out = torch.empty(self._shape, dtype=torch.float32, device=device)
+            out = torch.empty(self._shape, dtype=dense.dtype, device=device)
             with _span("decode_permute"):
-                _lib.check(lib.ndmps_decode_permute(plan.handle, dense.data_ptr(), out.data_ptr(), 4, stream))
+                _lib.check(lib.ndmps_decode_permute(plan.handle, dense.data_ptr(), out.data_ptr(), dense.element_size(),
+                                                    stream))
             if self.mode == "DCT":
                 n = self._shape[-1]
+                out = out.to(torch.float32)  # the IDCT kernel is fp32 (bf16 storage: upcast copy)
                 rec = torch.empty_like(out)
                 _lib.check(lib.ndmps_idct_last_f32(out.data_ptr(), rec.data_ptr(), plan.numel // n, n,
                                                    _dct_basis(n, device).data_ptr(), stream))
@@ -398,7 +416,7 @@ class NDMPS:
                 return None  # ndmps.py:150-153: unknown modes fall through
         if as_torch:
             return out if dtype is None else out.to(dtype)
-        return out.cpu().numpy()
+        return out.to(torch.float32).cpu().numpy()  # NumPy has no bf16
 
     # ---------------------------------------------------- quantise / on-disk size
     def compress_to_dtype(self, dtype=np.uint16, replace: bool = False):

@@ -311,9 +311,9 @@ int gemm_check(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, int tra
 // waves interleave 4-row k-steps and fold their accumulators through LDS; the slab result
 // goes to a partial buffer, reduced in fixed order (deterministic) by gram_reduce_kernel.
 // ----------------------------------------------------------------------------------
-template <int T>
+template <int T, typename TIN>
 __global__ void __launch_bounds__(256)
-gram_partial_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+gram_partial_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
                     double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab) {
   constexpr int TS = 16 * T;  // tile edge
   __shared__ double red[TS][TS + 1];
@@ -347,8 +347,8 @@ gram_partial_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t l
     for (int a = 0; a < T; ++a) {
       const int64_t ca = i0 + 16 * a + lc;
       const int64_t cb = j0 + 16 * a + lc;
-      av[a] = (row_ok && ca < n) ? (double)A[row * lda + ca] : 0.0;
-      bv[a] = (row_ok && cb < n) ? (double)A[row * lda + cb] : 0.0;
+      av[a] = (row_ok && ca < n) ? (double)(float)A[row * lda + ca] : 0.0;
+      bv[a] = (row_ok && cb < n) ? (double)(float)A[row * lda + cb] : 0.0;
     }
 #pragma unroll
     for (int a = 0; a < T; ++a)
@@ -449,9 +449,17 @@ constexpr int GW_KB = 32;    // rows per staged chunk
 
 // GW_TS: tile edge, 128 (n >= 128) or 64 (64 <= n < 128); each of the 2 x 2 waves owns a
 // (GW_TS/2)^2 sub-tile = (GW_TS/32)^2 MFMA accumulators
-template <int GW_TS>
+// four consecutive elements as fp32 (16-byte load for fp32 input, 8-byte load for bf16 input)
+__device__ __forceinline__ float4 load4_as_f32(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4_as_f32(const __bf16* p) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+template <int GW_TS, typename TIN>
 __global__ void __launch_bounds__(256)
-gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
                  double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab, int vec_ok) {
   constexpr int GW_LD = GW_TS + 16;
   constexpr int NT = GW_TS / 32;       // MFMA tiles per wave and direction
@@ -492,21 +500,21 @@ gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
       const int64_t row = r0 + rr;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
       if (row < r_end) {
-        const float* base = A + row * lda;
-        if (vec_ok && i0 + c4 + 3 < n) x = *reinterpret_cast<const float4*>(base + i0 + c4);
+        const TIN* base = A + row * lda;
+        if (vec_ok && i0 + c4 + 3 < n) x = load4_as_f32(base + i0 + c4);
         else {
-          if (i0 + c4 + 0 < n) x.x = base[i0 + c4 + 0];
-          if (i0 + c4 + 1 < n) x.y = base[i0 + c4 + 1];
-          if (i0 + c4 + 2 < n) x.z = base[i0 + c4 + 2];
-          if (i0 + c4 + 3 < n) x.w = base[i0 + c4 + 3];
+          if (i0 + c4 + 0 < n) x.x = (float)base[i0 + c4 + 0];
+          if (i0 + c4 + 1 < n) x.y = (float)base[i0 + c4 + 1];
+          if (i0 + c4 + 2 < n) x.z = (float)base[i0 + c4 + 2];
+          if (i0 + c4 + 3 < n) x.w = (float)base[i0 + c4 + 3];
         }
         if (!diag) {
-          if (vec_ok && j0 + c4 + 3 < n) y = *reinterpret_cast<const float4*>(base + j0 + c4);
+          if (vec_ok && j0 + c4 + 3 < n) y = load4_as_f32(base + j0 + c4);
           else {
-            if (j0 + c4 + 0 < n) y.x = base[j0 + c4 + 0];
-            if (j0 + c4 + 1 < n) y.y = base[j0 + c4 + 1];
-            if (j0 + c4 + 2 < n) y.z = base[j0 + c4 + 2];
-            if (j0 + c4 + 3 < n) y.w = base[j0 + c4 + 3];
+            if (j0 + c4 + 0 < n) y.x = (float)base[j0 + c4 + 0];
+            if (j0 + c4 + 1 < n) y.y = (float)base[j0 + c4 + 1];
+            if (j0 + c4 + 2 < n) y.z = (float)base[j0 + c4 + 2];
+            if (j0 + c4 + 3 < n) y.w = (float)base[j0 + c4 + 3];
           }
         }
       }
@@ -564,8 +572,9 @@ gram_wide_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda,
 // voxels): pure streaming.  One thread per row (grid-stride), the 36 products of a row go to
 // fp64 registers; wave shuffle + LDS fold; one partial per workgroup, summed in fixed order.
 // ----------------------------------------------------------------------------------
+template <typename TIN>
 __global__ void __launch_bounds__(256)
-gram_small_kernel(const float* __restrict__ A, int64_t m, int n, int64_t lda, double* __restrict__ partial,
+gram_small_kernel(const TIN* __restrict__ A, int64_t m, int n, int64_t lda, double* __restrict__ partial,
                   int vec_ok) {
   __shared__ double red[4][36];
   double acc[36];
@@ -574,13 +583,13 @@ gram_small_kernel(const float* __restrict__ A, int64_t m, int n, int64_t lda, do
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m; r += stride) {
     float x[8];
-    const float* row = A + r * lda;
+    const TIN* row = A + r * lda;
     if (vec_ok) {
-      const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+      const float4 a = load4_as_f32(row), b = load4_as_f32(row + 4);
       x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
     } else {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) x[c] = c < n ? row[c] : 0.f;
+      for (int c = 0; c < 8; ++c) x[c] = c < n ? (float)row[c] : 0.f;
     }
     int idx = 0;
 #pragma unroll
@@ -706,8 +715,10 @@ extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
   return (int64_t)(g.n_slabs + g.n_slabs / kReduceGroup + 2) * g.n_tiles * ts * ts * (int64_t)sizeof(double) + 256;
 }
 
-extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
-                              void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+namespace {
+template <typename TIN>
+int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, void* d_ws, int64_t ws_bytes,
+             ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_A && d_G, "NULL Gram operand");
   NDMPS_REQUIRE(m > 0 && n > 0 && lda >= n, "bad Gram extents m=%lld n=%lld lda=%lld", (long long)m,
                 (long long)n, (long long)lda);
@@ -718,10 +729,11 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
   }
   hipStream_t s = (hipStream_t)stream;
   double* partial = (double*)d_ws;
-  const int vec_ok = (lda % 4 == 0 && n % 4 == 0 && ((uintptr_t)d_A % 16) == 0) ? 1 : 0;
+  // four elements per load: 16 bytes of fp32, 8 bytes of bf16
+  const int vec_ok = (lda % 4 == 0 && n % 4 == 0 && ((uintptr_t)d_A % (4 * sizeof(TIN))) == 0) ? 1 : 0;
   if (gram_use_small(n)) {
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(m, 256 * 8), 1), kGramSmallBlocks);
-    hipLaunchKernelGGL(gram_small_kernel, dim3(blocks), dim3(256), 0, s, d_A, m, (int)n, lda, partial,
+    hipLaunchKernelGGL(gram_small_kernel<TIN>, dim3(blocks), dim3(256), 0, s, d_A, m, (int)n, lda, partial,
                        (vec_ok && n == 8) ? 1 : 0);
     hipLaunchKernelGGL(gram_small_reduce_kernel, dim3(1), dim3(256), 0, s, partial, blocks, d_G, (int)n);
     NDMPS_LAUNCH_CHECK();
@@ -731,12 +743,12 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
     GramGeom gw = gram_wide_geometry(m, n);
     NDMPS_REQUIRE(gw.n_slabs < 65536, "Gram slab count %d exceeds grid.y", gw.n_slabs);
     if (gram_wide_tile(n) == 128) {
-      hipLaunchKernelGGL(gram_wide_kernel<128>, dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
+      hipLaunchKernelGGL((gram_wide_kernel<128, TIN>), dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
                          partial, gw.tiles_1d, gw.rows_per_slab, vec_ok);
       NDMPS_LAUNCH_CHECK();
       return launch_tile_reduce<128>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
     }
-    hipLaunchKernelGGL(gram_wide_kernel<64>, dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
+    hipLaunchKernelGGL((gram_wide_kernel<64, TIN>), dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
                        partial, gw.tiles_1d, gw.rows_per_slab, vec_ok);
     NDMPS_LAUNCH_CHECK();
     return launch_tile_reduce<64>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
@@ -746,7 +758,7 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
   dim3 grid(g.n_tiles, g.n_slabs);
 #define NDMPS_GRAM(TT)                                                                              \
   do {                                                                                              \
-    hipLaunchKernelGGL(gram_partial_kernel<TT>, grid, dim3(256), 0, s, d_A, m, n, lda, partial,     \
+    hipLaunchKernelGGL((gram_partial_kernel<TT, TIN>), grid, dim3(256), 0, s, d_A, m, n, lda, partial, \
                        g.tiles_1d, g.rows_per_slab);                                                \
     NDMPS_LAUNCH_CHECK();                                                                           \
     return launch_tile_reduce<16 * TT>(partial, g.n_slabs, g.tiles_1d, g.n_tiles, d_G, n, s);       \
@@ -756,4 +768,16 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
   else NDMPS_GRAM(4);
 #undef NDMPS_GRAM
   return NDMPS_OK;
+}
+}  // namespace
+
+extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
+                              void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  return gram_any<float>(d_A, m, n, lda, d_G, d_ws, ws_bytes, stream);
+}
+
+// same with a bf16 matrix (products of two bf16 numbers are exact in fp32, let alone fp64)
+extern "C" int ndmps_gram_bf16(const void* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
+                               void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  return gram_any<__bf16>((const __bf16*)d_A, m, n, lda, d_G, d_ws, ws_bytes, stream);
 }

@@ -49,42 +49,46 @@ inline int grid1d(int64_t n) {
 }
 
 // ----------------------------------------------------------------------------- small kernels
-__global__ void __launch_bounds__(256) f32_to_f64_kernel(const float* __restrict__ x, int64_t n, double* y) {
+template <typename T = float>
+__global__ void __launch_bounds__(256) f32_to_f64_kernel(const T* __restrict__ x, int64_t n, double* y) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    y[i] = (double)x[i];
+    y[i] = (double)(float)x[i];
 }
 
 // core (k x n) fp32 <- first k columns of V (n x n fp64), transposed
+template <typename T = float>
 __global__ void __launch_bounds__(256)
-core_from_vectors_kernel(const double* __restrict__ V, int64_t n, int64_t k, float* __restrict__ core) {
+core_from_vectors_kernel(const double* __restrict__ V, int64_t n, int64_t k, T* __restrict__ core) {
   const int64_t total = k * n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t i = e / n, c = e % n;
-    core[e] = (float)V[c * n + i];
+    core[e] = (T)(float)V[c * n + i];
   }
 }
 
 // out (rows x k) fp32 <- M (rows x ldm fp64)[:, :k] * scale[col]^power
+template <typename T = float>
 __global__ void __launch_bounds__(256)
 scale_cols_to_f32_kernel(const double* __restrict__ M, int64_t rows, int64_t ldm, int64_t k,
-                         const double* __restrict__ sigma, double power, float* __restrict__ out) {
+                         const double* __restrict__ sigma, double power, T* __restrict__ out) {
   const int64_t total = rows * k;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t r = e / k, c = e % k;
     const double sg = sigma[c];
-    out[e] = (float)(sg > 0.0 ? M[r * ldm + c] * pow(sg, power) : 0.0);
+    out[e] = (T)(float)(sg > 0.0 ? M[r * ldm + c] * pow(sg, power) : 0.0);
   }
 }
 
 // out (k x n) fp32 <- M (k x n fp64) with row i scaled by sigma[i]^power
+template <typename T = float>
 __global__ void __launch_bounds__(256)
 scale_rows_to_f32_kernel(const double* __restrict__ M, int64_t k, int64_t n, const double* __restrict__ sigma,
-                         double power, float* __restrict__ out) {
+                         double power, T* __restrict__ out) {
   const int64_t total = k * n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
   {
     const double sg = sigma[e / n];
-    out[e] = (float)(sg > 0.0 ? M[e] * pow(sg, power) : 0.0);
+    out[e] = (T)(float)(sg > 0.0 ? M[e] * pow(sg, power) : 0.0);
   }
 }
 
@@ -163,9 +167,10 @@ merge_stage2_kernel(const double* __restrict__ T, int64_t stride_t, const double
 
 // W_i (N_i x k_i, ld ldw) = B V_i:  W_i[(a, c')][p] = sum_q W_{i+1}[c'][q] V[(a k_{i+1} + q)][p]   (V: n_i x n_i, ld n_i)
 // optionally also as fp32 (ld = k_i, compact) for the projection GEMM
+template <typename T>
 __global__ void __launch_bounds__(256)
 merge_basis_kernel(const double* __restrict__ Wr, int64_t stride_w, int ldw, const double* __restrict__ V,
-                   int64_t stride_v, double* __restrict__ Wout, float* __restrict__ W32, int64_t stride_w32,
+                   int64_t stride_v, double* __restrict__ Wout, T* __restrict__ W32, int64_t stride_w32,
                    int n_right, int d_i, MergeRanks rk) {
   const int b = blockIdx.y;
   const int kr = rk.k_right[b], kh = rk.k_here[b];
@@ -173,7 +178,7 @@ merge_basis_kernel(const double* __restrict__ Wr, int64_t stride_w, int ldw, con
   const double* Wb = Wr + (int64_t)b * stride_w;
   const double* Vb = V + (int64_t)b * stride_v;
   double* Ob = Wout + (int64_t)b * stride_w;
-  float* O32 = W32 ? W32 + (int64_t)b * stride_w32 : nullptr;
+  T* O32 = W32 ? W32 + (int64_t)b * stride_w32 : nullptr;
   const int64_t total = (int64_t)d_i * n_right * kh;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int row = (int)(e / kh), pp = (int)(e % kh);
@@ -181,7 +186,7 @@ merge_basis_kernel(const double* __restrict__ Wr, int64_t stride_w, int ldw, con
     double acc = 0.0;
     for (int q = 0; q < kr; ++q) acc = fma(Wb[(int64_t)c * ldw + q], Vb[(int64_t)(a * kr + q) * n + pp], acc);
     Ob[(int64_t)row * ldw + pp] = acc;
-    if (O32) O32[(int64_t)row * kh + pp] = (float)acc;
+    if (O32) O32[(int64_t)row * kh + pp] = (T)(float)acc;
   }
 }
 
@@ -255,6 +260,7 @@ struct SweepLayout {
   int merge_from = 0;         // first site of the merged trailing run (== L: none)
   int64_t merge_n = 0;        // order of its raw Gram matrix
   int64_t merge_w = 0;        // leading dimension of the accumulated bases
+  int64_t transpose_bytes = 0;  // bf16 path: transposed copy of the merged basis
   int64_t workspace = 0;      // for the batch size it was computed for
 };
 
@@ -310,7 +316,9 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_n);      // T = Graw B
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_w);      // accumulated basis W (ping)
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_w);      // (pong)
-  used = arena_bytes(used, 4, (int64_t)batch * out.merge_n * out.merge_w);      // fp32 copy for the projection
+  used = arena_bytes(used, 4, (int64_t)batch * out.merge_n * out.merge_w);      // fp32 / bf16 copy for the projection
+  out.transpose_bytes = ndmps_gemm_bf16_workspace_bytes(0, std::max<int64_t>(out.merge_w, 1), std::max<int64_t>(out.merge_n, 1));
+  used = arena_bytes(used, 1, out.transpose_bytes);
   out.workspace = ndmps::round_up(used, 256) + 256;
   return NDMPS_OK;
 }
@@ -342,11 +350,28 @@ extern "C" int64_t ndmps_tt_sweep_batched_workspace_bytes(int batch, int L, cons
 // All volumes of the batch have the same site dims; they advance through the sites in lockstep
 // so that every site's eigenproblems are solved by ONE batched Jacobi (its sequential depth is
 // the cost of the path); Gram / projection launches stay per volume (they fill the chip alone).
-extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const int64_t* h_dims,
-                                          double cutoff, int64_t max_bond, float* const* h_cores,
-                                          const int64_t* h_core_offsets, int64_t* h_bonds_out,
-                                          double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
-                                          int64_t ws_bytes, ndmps_stream_t stream) {
+namespace {
+// element-type dispatch of the two streaming products of the sweep
+inline int gram_T(const float* A, int64_t m, int64_t n, int64_t lda, double* G, void* ws, int64_t wsb, hipStream_t s) {
+  return ndmps_gram_f32(A, m, n, lda, G, ws, wsb, s);
+}
+inline int gram_T(const __bf16* A, int64_t m, int64_t n, int64_t lda, double* G, void* ws, int64_t wsb, hipStream_t s) {
+  return ndmps_gram_bf16(A, m, n, lda, G, ws, wsb, s);
+}
+// C (m, n) = A (m, k) op(B);  tws: scratch of the bf16 path (transposed copy of a (k, n) right operand)
+inline int gemm_T(int transB, int64_t m, int64_t n, int64_t k, const float* A, const float* B, int64_t ldb, float* C,
+                  void*, int64_t, hipStream_t s) {
+  return ndmps_sgemm(0, transB, m, n, k, A, k, B, ldb, C, n, s);
+}
+inline int gemm_T(int transB, int64_t m, int64_t n, int64_t k, const __bf16* A, const __bf16* B, int64_t ldb, __bf16* C,
+                  void* tws, int64_t tws_bytes, hipStream_t s) {
+  return ndmps_gemm_bf16(transB, m, n, k, A, k, B, ldb, C, n, tws, tws_bytes, s);
+}
+
+template <typename T>
+int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, double cutoff, int64_t max_bond,
+               T* const* h_cores, const int64_t* h_core_offsets, int64_t* h_bonds_out, double* h_spectra,
+               const int64_t* h_spec_offsets, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(h_dense && h_dims && h_cores && h_core_offsets && h_bonds_out, "NULL sweep argument");
   NDMPS_REQUIRE(cutoff >= 0.0, "cutoff must be non-negative");
   SweepLayout lay;
@@ -359,7 +384,7 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
   hipStream_t s = (hipStream_t)stream;
   const int64_t sq = lay.small_max * lay.small_max;
   Arena ar(d_ws, ws_bytes);
-  float* other = ar.take<float>((int64_t)batch * lay.numel);
+  T* other = ar.take<T>((int64_t)batch * lay.numel);
   double* G = ar.take<double>((int64_t)batch * sq);
   double* V = ar.take<double>((int64_t)batch * sq);
   double* w = ar.take<double>((int64_t)batch * lay.small_max);
@@ -375,10 +400,12 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
   double* Tm = ar.take<double>((int64_t)batch * lay.merge_n * lay.merge_n);
   double* Wm[2] = {ar.take<double>((int64_t)batch * lay.merge_n * lay.merge_w),
                    ar.take<double>((int64_t)batch * lay.merge_n * lay.merge_w)};
-  float* W32 = ar.take<float>((int64_t)batch * lay.merge_n * lay.merge_w);
-  NDMPS_REQUIRE(Graw && Tm && Wm[0] && Wm[1] && W32, "workspace carve failed");
+  T* W32 = ar.take<T>((int64_t)batch * lay.merge_n * lay.merge_w);
+  const int64_t tws_bytes = lay.transpose_bytes;
+  char* tws = ar.take<char>(tws_bytes);
+  NDMPS_REQUIRE(Graw && Tm && Wm[0] && Wm[1] && W32 && tws, "workspace carve failed");
 
-  std::vector<float*> cur(batch), nxt(batch);
+  std::vector<T*> cur(batch), nxt(batch);
   std::vector<int64_t> chi_r(batch, 1), cur_elems(batch, lay.numel), eig_n(batch), kept(batch);
   for (int b = 0; b < batch; ++b) {
     cur[b] = h_dense[b];
@@ -443,7 +470,7 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
     const int64_t n0 = lay.merge_n, ldw = lay.merge_w, m0 = lay.numel / n0;
     const int64_t stride_top = n0 * n0, stride_w = n0 * ldw;
     for (int b = 0; b < batch; ++b)
-      NDMPS_TRY(ndmps_gram_f32(cur[b], m0, n0, n0, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
+      NDMPS_TRY(gram_T(cur[b], m0, n0, n0, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
     hipLaunchKernelGGL(merge_basis_init_kernel, dim3(batch), dim3(1), 0, s, Wm[0], stride_w);
     NDMPS_LAUNCH_CHECK();
     int wcur = 0;
@@ -480,14 +507,14 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
           biggest = std::max(biggest, kept[base + t]);
         }
         const int g3 = (int)std::min<int64_t>(ceil_div(n_i * biggest, 256), 1024);
-        hipLaunchKernelGGL(merge_basis_kernel, dim3(g3, count), dim3(256), 0, s, Wm[wcur] + base * stride_w, stride_w,
+        hipLaunchKernelGGL(merge_basis_kernel<T>, dim3(g3, count), dim3(256), 0, s, Wm[wcur] + base * stride_w, stride_w,
                            (int)ldw, V + base * sq, sq, Wm[wcur ^ 1] + base * stride_w,
-                           i == i0 ? W32 + base * stride_w : nullptr, stride_w, (int)n_right, (int)d_i, rk);
+                           i == i0 ? W32 + base * stride_w : (T*)nullptr, stride_w, (int)n_right, (int)d_i, rk);
       }
       NDMPS_LAUNCH_CHECK();
       for (int b = 0; b < batch; ++b) {
         const int64_t n = eig_n[b], k = kept[b];
-        hipLaunchKernelGGL(core_from_vectors_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, V + (int64_t)b * sq, n, k,
+        hipLaunchKernelGGL(core_from_vectors_kernel<T>, dim3(grid1d(k * n)), dim3(256), 0, s, V + (int64_t)b * sq, n, k,
                            h_cores[b] + h_core_offsets[i]);
         chi_r[b] = k;
         h_bonds_out[(int64_t)b * (L + 1) + i] = k;
@@ -498,7 +525,7 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
     }
     for (int b = 0; b < batch; ++b) {  // carry = A_raw W (m0 x k)
       const int64_t k = chi_r[b];
-      NDMPS_TRY(ndmps_sgemm(0, 0, m0, k, n0, cur[b], n0, W32 + (int64_t)b * stride_w, k, nxt[b], k, s));
+      NDMPS_TRY(gemm_T(0, m0, k, n0, cur[b], W32 + (int64_t)b * stride_w, k, nxt[b], tws, tws_bytes, s));
       std::swap(cur[b], nxt[b]);
       cur_elems[b] = m0 * k;
     }
@@ -517,10 +544,10 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
         const int64_t need = ndmps_gram_workspace_bytes(m, n);
         NDMPS_REQUIRE(need <= lay.gram_ws, "internal: Gram workspace bound violated (%lld > %lld)",
                       (long long)need, (long long)lay.gram_ws);
-        NDMPS_TRY(ndmps_gram_f32(cur[b], m, n, n, Gb, gram_ws, lay.gram_ws, s));
+        NDMPS_TRY(gram_T(cur[b], m, n, n, Gb, gram_ws, lay.gram_ws, s));
       } else {
         double* Ab = A64 + (int64_t)b * lay.wide_elems;
-        hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(m * n)), dim3(256), 0, s, cur[b], m * n, Ab);
+        hipLaunchKernelGGL(f32_to_f64_kernel<T>, dim3(grid1d(m * n)), dim3(256), 0, s, cur[b], m * n, Ab);
         NDMPS_LAUNCH_CHECK();
         NDMPS_TRY(ndmps_dgemm(0, 1, m, m, n, Ab, n, Ab, n, Gb, m, s));
       }
@@ -531,22 +558,22 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
       const int64_t n = h_dims[i] * chi_r[b];
       const int64_t small = eig_n[b];
       const int64_t k = kept[b];
-      float* core = h_cores[b] + h_core_offsets[i];
+      T* core = h_cores[b] + h_core_offsets[i];
       double* Vb = V + (int64_t)b * sq;
       double* wb = w + (int64_t)b * lay.small_max;
       double* sigb = sig + (int64_t)b * lay.small_max;
       if (n <= m) {
-        hipLaunchKernelGGL(core_from_vectors_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, Vb, n, k, core);
+        hipLaunchKernelGGL(core_from_vectors_kernel<T>, dim3(grid1d(k * n)), dim3(256), 0, s, Vb, n, k, core);
         NDMPS_LAUNCH_CHECK();
-        NDMPS_TRY(ndmps_sgemm(0, 1, m, k, n, cur[b], n, core, n, nxt[b], k, s));
+        NDMPS_TRY(gemm_T(1, m, k, n, cur[b], core, n, nxt[b], tws, tws_bytes, s));
       } else {
         double* Ab = A64 + (int64_t)b * lay.wide_elems;
         hipLaunchKernelGGL(sqrt_clamp_kernel, dim3(grid1d(small)), dim3(256), 0, s, wb, small, sigb);
-        hipLaunchKernelGGL(scale_cols_to_f32_kernel, dim3(grid1d(m * k)), dim3(256), 0, s, Vb, m, m, k, sigb, 1.0,
+        hipLaunchKernelGGL(scale_cols_to_f32_kernel<T>, dim3(grid1d(m * k)), dim3(256), 0, s, Vb, m, m, k, sigb, 1.0,
                            nxt[b]);  // carry = U_k diag(sigma_k)
         NDMPS_LAUNCH_CHECK();
         NDMPS_TRY(ndmps_dgemm(1, 0, k, n, m, Vb, m, Ab, n, UtA, n, s));
-        hipLaunchKernelGGL(scale_rows_to_f32_kernel, dim3(grid1d(k * n)), dim3(256), 0, s, UtA, k, n, sigb, -1.0,
+        hipLaunchKernelGGL(scale_rows_to_f32_kernel<T>, dim3(grid1d(k * n)), dim3(256), 0, s, UtA, k, n, sigb, -1.0,
                            core);  // core = diag(1/sigma_k) U_k^T A
         NDMPS_LAUNCH_CHECK();
       }
@@ -558,10 +585,32 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
   }
   // site 0 carries the norm: (1, d_0, chi_1)
   for (int b = 0; b < batch; ++b)
-    NDMPS_CHECK_HIP(hipMemcpyAsync(h_cores[b] + h_core_offsets[0], cur[b], cur_elems[b] * sizeof(float),
+    NDMPS_CHECK_HIP(hipMemcpyAsync(h_cores[b] + h_core_offsets[0], cur[b], cur_elems[b] * sizeof(T),
                                    hipMemcpyDeviceToDevice, s));
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   return NDMPS_OK;
+}
+}  // namespace
+
+extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const int64_t* h_dims,
+                                          double cutoff, int64_t max_bond, float* const* h_cores,
+                                          const int64_t* h_core_offsets, int64_t* h_bonds_out,
+                                          double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
+                                          int64_t ws_bytes, ndmps_stream_t stream) {
+  return sweep_impl<float>(batch, h_dense, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets, h_bonds_out, h_spectra,
+                           h_spec_offsets, d_ws, ws_bytes, stream);
+}
+
+// bf16 storage: the site-order tensors, the carried matrices and the cores are bf16 in HBM; Gram matrices,
+// eigen-decompositions and bases stay fp64, products accumulate in fp32 on the bf16 MFMA.  Same layout and
+// workspace queries as the fp32 sweep (offsets in elements; the fp32 workspace size is an upper bound).
+extern "C" int ndmps_tt_sweep_batched_bf16(int batch, void* const* h_dense, int L, const int64_t* h_dims,
+                                           double cutoff, int64_t max_bond, void* const* h_cores,
+                                           const int64_t* h_core_offsets, int64_t* h_bonds_out,
+                                           double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
+                                           int64_t ws_bytes, ndmps_stream_t stream) {
+  return sweep_impl<__bf16>(batch, (__bf16* const*)h_dense, L, h_dims, cutoff, max_bond, (__bf16* const*)h_cores,
+                            h_core_offsets, h_bonds_out, h_spectra, h_spec_offsets, d_ws, ws_bytes, stream);
 }
 
 extern "C" int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cutoff,
@@ -650,7 +699,7 @@ extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int
 
   int sweeps = 0;
   NDMPS_TRY(ndmps_gram_f32(d_t1, m1, chi, chi, G1, gram_ws, gram_bytes, s));
-  hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(chi * n2)), dim3(256), 0, s, d_t2, chi * n2, t2d);
+  hipLaunchKernelGGL(f32_to_f64_kernel<float>, dim3(grid1d(chi * n2)), dim3(256), 0, s, d_t2, chi * n2, t2d);
   NDMPS_LAUNCH_CHECK();
   NDMPS_TRY(ndmps_dgemm(0, 1, chi, chi, n2, t2d, n2, t2d, n2, G2, chi, s));
   NDMPS_TRY(ndmps_syevj_f64(G2, chi, Lt, w2, ev_ws, ev_bytes, &sweeps, s));
@@ -672,8 +721,8 @@ extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int
   NDMPS_LAUNCH_CHECK();
   NDMPS_TRY(ndmps_dgemm(0, 0, chi, k, chi, Lt, chi, V, chi, P1, k, s));
   NDMPS_TRY(ndmps_dgemm(0, 0, chi, k, chi, tmp, chi, V, chi, P2, k, s));
-  hipLaunchKernelGGL(scale_cols_to_f32_kernel, dim3(grid1d(chi * k)), dim3(256), 0, s, P1, chi, k, k, sig, -0.5, A1);
-  hipLaunchKernelGGL(scale_cols_to_f32_kernel, dim3(grid1d(chi * k)), dim3(256), 0, s, P2, chi, k, k, sig, -1.5, B2);
+  hipLaunchKernelGGL(scale_cols_to_f32_kernel<float>, dim3(grid1d(chi * k)), dim3(256), 0, s, P1, chi, k, k, sig, -0.5, A1);
+  hipLaunchKernelGGL(scale_cols_to_f32_kernel<float>, dim3(grid1d(chi * k)), dim3(256), 0, s, P2, chi, k, k, sig, -1.5, B2);
   NDMPS_LAUNCH_CHECK();
   NDMPS_TRY(ndmps_sgemm(0, 0, m1, k, chi, d_t1, chi, A1, k, d_new1, k, s));      // (chi_l d1, k)
   NDMPS_TRY(ndmps_sgemm(1, 0, k, n2, chi, B2, k, d_t2, n2, d_new2, n2, s));      // (k, d2 chi_r)
@@ -722,12 +771,17 @@ ChainPlan chain_plan(int L, const int64_t* dims, const int64_t* bonds) {
 extern "C" int64_t ndmps_chain_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds) {
   if (L < 1 || !h_dims || !h_bonds) return 0;
   const ChainPlan p = chain_plan(L, h_dims, h_bonds);
-  return (ndmps::round_up(p.left_elems, 64) + 2 * ndmps::round_up(p.tail_elems, 64)) * (int64_t)sizeof(float) + 512;
+  // + room for the transposed right operand of a bf16 product (a core or a tail matrix)
+  int64_t biggest_b = p.tail_elems;
+  for (int i = 0; i < L; ++i) biggest_b = std::max(biggest_b, h_bonds[i] * h_dims[i] * h_bonds[i + 1]);
+  return (ndmps::round_up(p.left_elems, 64) + 2 * ndmps::round_up(p.tail_elems, 64)) * (int64_t)sizeof(float) +
+         ndmps::round_up(biggest_b * 2, 256) + 1024;
 }
 
-extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int64_t* h_bonds,
-                                        const float* const* h_cores, float* d_dense, void* d_ws,
-                                        int64_t ws_bytes, ndmps_stream_t stream) {
+namespace {
+template <typename T>
+int chain_impl(int L, const int64_t* h_dims, const int64_t* h_bonds, const T* const* h_cores, T* d_dense, void* d_ws,
+               int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(L >= 1 && h_dims && h_bonds && h_cores && d_dense, "bad chain argument");
   NDMPS_REQUIRE(h_bonds[0] == 1 && h_bonds[L] == 1, "open boundary bonds must be 1");
   int64_t numel = 1;
@@ -753,24 +807,28 @@ extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int6
   }
   hipStream_t s = (hipStream_t)stream;
   if (L == 1) {
-    NDMPS_CHECK_HIP(hipMemcpyAsync(d_dense, h_cores[0], numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+    NDMPS_CHECK_HIP(hipMemcpyAsync(d_dense, h_cores[0], numel * sizeof(T), hipMemcpyDeviceToDevice, s));
     return NDMPS_OK;
   }
   const ChainPlan p = chain_plan(L, h_dims, h_bonds);
-  float* ws_left = (float*)d_ws;
-  float* ws_tail[2] = {ws_left + ndmps::round_up(p.left_elems, 64),
-                       ws_left + ndmps::round_up(p.left_elems, 64) + ndmps::round_up(p.tail_elems, 64)};
+  T* ws_left = (T*)d_ws;
+  T* ws_tail[2] = {ws_left + ndmps::round_up(p.left_elems, 64),
+                   ws_left + ndmps::round_up(p.left_elems, 64) + ndmps::round_up(p.tail_elems, 64)};
+  // scratch behind the three buffers (bf16: transposed right operands)
+  char* tws = (char*)(ws_tail[1] + ndmps::round_up(p.tail_elems, 64));
+  tws += (256 - ((uintptr_t)tws & 255)) & 255;
+  const int64_t tws_bytes = ((char*)d_ws + ws_bytes) - tws;
   const int j0 = p.j0;
   // ---- tail, right to left: R_i (k_i x N_i) = [core_i as (k_i d_i) x k_{i+1}] R_{i+1}
-  const float* R = nullptr;
+  const T* R = nullptr;
   int64_t n_tail = 1;
   if (j0 < L) {
     R = h_cores[L - 1];
     n_tail = h_dims[L - 1];
     int t = 0;
     for (int i = L - 2; i >= j0; --i) {
-      NDMPS_TRY(ndmps_sgemm(0, 0, h_bonds[i] * h_dims[i], n_tail, h_bonds[i + 1], h_cores[i], h_bonds[i + 1], R, n_tail,
-                            ws_tail[t], n_tail, s));
+      NDMPS_TRY(gemm_T(0, h_bonds[i] * h_dims[i], n_tail, h_bonds[i + 1], h_cores[i], R, n_tail, ws_tail[t], tws,
+                       tws_bytes, s));
       R = ws_tail[t];
       t ^= 1;
       n_tail *= h_dims[i];
@@ -779,21 +837,34 @@ extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int6
   // ---- left part, cumulative: Left_i (rows_i x k_{i+1}); the last product of the whole chain writes d_dense,
   //      the one before it must therefore land in the workspace
   const int last_left = j0 < L ? j0 - 1 : L - 1;  // index of the last cumulative GEMM (site index), 0: none
-  const float* left = h_cores[0];
+  const T* left = h_cores[0];
   int64_t rows = h_dims[0];
   for (int i = 1; i <= last_left; ++i) {
     const int64_t chi = h_bonds[i], cols = h_dims[i] * h_bonds[i + 1];
     // products remaining after this one (cumulative ones + the final Left R)
     const int remaining = (last_left - i) + (j0 < L ? 1 : 0);
-    float* out = remaining % 2 == 0 ? d_dense : ws_left;
-    NDMPS_TRY(ndmps_sgemm(0, 0, rows, cols, chi, left, chi, h_cores[i], cols, out, cols, s));
+    T* out = remaining % 2 == 0 ? d_dense : ws_left;
+    NDMPS_TRY(gemm_T(0, rows, cols, chi, left, h_cores[i], cols, out, tws, tws_bytes, s));
     left = out;
     rows *= h_dims[i];
   }
   if (j0 < L)
-    NDMPS_TRY(ndmps_sgemm(0, 0, rows, n_tail, h_bonds[j0], left, h_bonds[j0], R, n_tail, d_dense, n_tail, s));
+    NDMPS_TRY(gemm_T(0, rows, n_tail, h_bonds[j0], left, R, n_tail, d_dense, tws, tws_bytes, s));
   NDMPS_REQUIRE(j0 < L || left == d_dense, "internal: chain result landed in the wrong buffer");
   return NDMPS_OK;
+}
+}  // namespace
+
+extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                                        const float* const* h_cores, float* d_dense, void* d_ws,
+                                        int64_t ws_bytes, ndmps_stream_t stream) {
+  return chain_impl<float>(L, h_dims, h_bonds, h_cores, d_dense, d_ws, ws_bytes, stream);
+}
+
+extern "C" int ndmps_chain_contract_bf16(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                                         const void* const* h_cores, void* d_dense, void* d_ws,
+                                         int64_t ws_bytes, ndmps_stream_t stream) {
+  return chain_impl<__bf16>(L, h_dims, h_bonds, (const __bf16* const*)h_cores, (__bf16*)d_dense, d_ws, ws_bytes, stream);
 }
 
 // =================================================================== overlap
@@ -850,8 +921,8 @@ extern "C" int ndmps_overlap_f32(int L, const int64_t* h_dims, const int64_t* h_
     const int64_t ca = h_bonds_a[i], ca2 = h_bonds_a[i + 1];
     const int64_t cb = h_bonds_b[i], cb2 = h_bonds_b[i + 1];
     const int64_t d = h_dims[i];
-    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(ca * d * ca2)), dim3(256), 0, s, h_cores_a[i], ca * d * ca2, A);
-    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid1d(cb * d * cb2)), dim3(256), 0, s, h_cores_b[i], cb * d * cb2, B);
+    hipLaunchKernelGGL(f32_to_f64_kernel<float>, dim3(grid1d(ca * d * ca2)), dim3(256), 0, s, h_cores_a[i], ca * d * ca2, A);
+    hipLaunchKernelGGL(f32_to_f64_kernel<float>, dim3(grid1d(cb * d * cb2)), dim3(256), 0, s, h_cores_b[i], cb * d * cb2, B);
     NDMPS_LAUNCH_CHECK();
     // X (cb, d ca2) = E^T (cb, ca) A (ca, d ca2)
     NDMPS_TRY(ndmps_dgemm(1, 0, cb, d * ca2, ca, E[cur], cb, A, d * ca2, X, d * ca2, s));

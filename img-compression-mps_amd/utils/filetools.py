@@ -30,11 +30,20 @@ def _bits(dtype) -> int:
     raise ValueError(f"Unsupported dtype {dtype!r}: the device path quantises to uint8 or uint16")
 
 
+def _f32(t):
+    """fp32 view of a core for the fp32 reduction / quantisation kernels (bf16 cores are a few MB at most:
+    the upcast copy is plumbing, not a data path)."""
+    import torch
+
+    return t if t.dtype == torch.float32 else t.to(torch.float32)
+
+
 def minmax(t):
-    """(min, max) of a device fp32 tensor as Python floats."""
+    """(min, max) of a device tensor as Python floats."""
     import torch
 
     lib = _lib.load()
+    t = _f32(t)
     ws = torch.empty(lib.ndmps_reduce_workspace_bytes(), dtype=torch.uint8, device=t.device)
     lo, hi = C.c_float(), C.c_float()
     t = t.contiguous()
@@ -49,7 +58,7 @@ def minmax_many(tensors, with_sumsq=False):
     import torch
 
     lib = _lib.load()
-    ts = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+    ts = [_f32(t) if _f32(t).is_contiguous() else _f32(t).contiguous() for t in tensors]
     count = len(ts)
     if count == 0:
         return ([], []) if with_sumsq else []
@@ -70,7 +79,7 @@ def scale_to_dtype(t, dtype=np.uint8):
 
     bits = _bits(dtype)
     lib = _lib.load()
-    t = t.contiguous()
+    t = _f32(t).contiguous()
     lo, hi = minmax(t)
     # torch has no uint16 arithmetic, but int16 storage has the same bytes
     q = torch.empty(t.shape, dtype=torch.uint8 if bits == 8 else torch.int16, device=t.device)

@@ -126,6 +126,19 @@ int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const d
 int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n);
 int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
                    void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+/* bf16 storage path (BASELINE config 5; the reference fixes its dtype at core/ndmps.py:56).
+ * ndmps_gemm_bf16: C (m, n) = A (m, k) op(B), op(B) = B (k, n) for transB == 0 and B^T with B (n, k) for
+ * transB == 1; A, B, C bf16 row-major, fp32 accumulation on v_mfma_f32_32x32x16_bf16.  d_ws:
+ * ndmps_gemm_bf16_workspace_bytes(transB, n, k) bytes (a (k, n) right operand is transposed first). */
+int64_t ndmps_gemm_bf16_workspace_bytes(int transB, int64_t n, int64_t k);
+int ndmps_gemm_bf16(int transB, int64_t m, int64_t n, int64_t k, const void* d_A, int64_t lda,
+                    const void* d_B, int64_t ldb, void* d_C, int64_t ldc, void* d_ws, int64_t ws_bytes,
+                    ndmps_stream_t stream);
+/* G = A^T A for a bf16 matrix A (products exact, fp64 accumulation); workspace as ndmps_gram_f32 */
+int ndmps_gram_bf16(const void* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, void* d_ws,
+                    int64_t ws_bytes, ndmps_stream_t stream);
+int ndmps_convert_bf16_to_f32(const void* d_x, int64_t n, float* d_y, ndmps_stream_t stream);
+int ndmps_convert_f32_to_bf16(const float* d_x, int64_t n, void* d_y, ndmps_stream_t stream);
 /* symmetric eigen-decomposition (block two-sided Jacobi, fp64): G = V diag(w) V^T,
  * w descending, eigenvectors in the COLUMNS of V, each with its largest-magnitude
  * component positive.  d_G is destroyed.  Synchronises the stream. */
@@ -211,6 +224,15 @@ int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const in
                                double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
                                int64_t ws_bytes, ndmps_stream_t stream);
 
+/* The same sweep on bf16 storage: site-order tensors, carried matrices and cores are bf16 in HBM, Gram
+ * matrices / eigen-decompositions / bases fp64, products fp32-accumulated on the bf16 MFMA.  Layout and
+ * workspace queries are those of the fp32 sweep (offsets count elements; its workspace size is an upper bound). */
+int ndmps_tt_sweep_batched_bf16(int batch, void* const* h_dense, int L, const int64_t* h_dims,
+                                double cutoff, int64_t max_bond, void* const* h_cores,
+                                const int64_t* h_core_offsets, int64_t* h_bonds_out,
+                                double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
+                                int64_t ws_bytes, ndmps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Bond truncation: replaces quimb tensor_compress_bond(t1, t2, cutoff, cutoff_mode="rel")
  * (core/ndmps.py:104-106; reduced=True, absorb="both").  t1 (chi_l, d1, chi),
@@ -233,6 +255,12 @@ int64_t ndmps_chain_workspace_bytes(int L, const int64_t* h_dims, const int64_t*
 int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int64_t* h_bonds,
                              const float* const* h_cores, float* d_dense, void* d_ws,
                              int64_t ws_bytes, ndmps_stream_t stream);
+
+/* bf16 cores in, bf16 tensor out, fp32 accumulation (v_mfma_f32_32x32x16_bf16); workspace:
+ * ndmps_chain_workspace_bytes (the fp32 size covers the bf16 intermediates and the transposed operands) */
+int ndmps_chain_contract_bf16(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                              const void* const* h_cores, void* d_dense, void* d_ws,
+                              int64_t ws_bytes, ndmps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Overlap: replaces `mps @ mps` (core/ndmps.py:76,86; utils/metrics.py:160), real data,

@@ -788,7 +788,7 @@ def _projection_checks(x, obj, rec, tol=2e-4):
     nx, nr, ne = float((x64 * x64).sum()), float((r64 * r64).sum()), float(((x64 - r64) ** 2).sum())
     assert abs(nx - nr - ne) <= tol * nx
     assert abs(float(((x64 - r64) * r64).sum())) <= tol * nx
-    assert math.isclose(obj.norm_value ** 2, nr, rel_tol=1e-4)
+    assert math.isclose(obj.norm_value ** 2, nr, rel_tol=max(1e-4, tol))
     return ne / nx
 
 
@@ -867,7 +867,8 @@ def test_config4_batch_of_128_cubed_chi32_matches_oracle_on_samples():
 
 def test_config5_shape_4d_fmri_chi128_fp32_properties():
     """BASELINE configs[4] geometry (128x128x64x256, site dims 64,32,16,16,16,32, chi = 128) in fp32
-    storage (bf16 storage is not built this round): eigenproblems up to 2048 x 2048."""
+    storage (the bf16 storage the config names: test_config5_full_size_bf16_storage_chi128_properties):
+    eigenproblems up to 2048 x 2048."""
     g = torch.Generator(device=DEV).manual_seed(7)
     ax = [torch.linspace(-1, 1, n, device=DEV) for n in (128, 128, 64)]
     vol = torch.zeros((128, 128, 64), device=DEV)
@@ -906,6 +907,101 @@ def test_bf16_volume_in_and_out():
     rb = obj.to_tensor(as_torch=True, dtype=torch.bfloat16)
     assert rb.dtype == torch.bfloat16 and rb.shape == xb.shape
     assert float((rb.float() - r32).abs().max()) <= 2.0 ** -8 * float(r32.abs().max())
+
+
+# ------------------------------------------------------------------ bf16 storage path (BASELINE configs[4])
+# Tolerance of everything below: bf16 keeps 8 significant bits, every stored value (volume, carried matrix,
+# core, chain intermediate, reconstruction) is rounded to 2^-9 relative; a reconstruction goes through ~2 L of
+# them, so results are compared at 2e-2 relative (fp32 accumulation errors are four orders smaller).
+BF16_TOL = 2e-2
+
+
+@pytest.mark.parametrize("m,n,k,transB", [(128, 128, 64, 1), (1000, 130, 70, 0), (4097, 256, 128, 0), (300, 8, 8, 1),
+                                           (64, 512, 32, 0), (5, 3, 2, 1)])
+def test_gemm_bf16_against_fp32_products(m, n, k, transB):
+    """v_mfma_f32_32x32x16_bf16 GEMM: bf16 operands, fp32 accumulation, bf16 result; both layouts of the right
+    operand, ragged extents, against the fp32 product of the same bf16 values rounded once."""
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    a = torch.randn((m, k), device=DEV, generator=g).to(torch.bfloat16)
+    b = torch.randn((n, k) if transB else (k, n), device=DEV, generator=g).to(torch.bfloat16)
+    c = torch.full((m, n), float("nan"), device=DEV, dtype=torch.bfloat16)
+    nbytes = lib.ndmps_gemm_bf16_workspace_bytes(transB, n, k)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ndmps_gemm_bf16(transB, m, n, k, a.data_ptr(), k, b.data_ptr(), k if transB else n, c.data_ptr(), n,
+                                   ws.data_ptr(), nbytes, sp()))
+    ref = a.float() @ (b.float().T if transB else b.float())
+    assert torch.isfinite(c.float()).all()
+    err = (c.float() - ref).abs()
+    assert float((err / (ref.abs() + math.sqrt(k))).max()) <= 2.0 ** -8  # one bf16 rounding of the fp32 sum
+
+
+def test_gram_bf16_is_exact_in_fp64():
+    lib = _lib.load()
+    for m, n in ((5000, 8), (4096, 40), (3000, 512), (700, 130)):
+        a = torch.randn((m, n), device=DEV).to(torch.bfloat16)
+        g = torch.empty((n, n), dtype=torch.float64, device=DEV)
+        nbytes = lib.ndmps_gram_workspace_bytes(m, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.ndmps_gram_bf16(a.data_ptr(), m, n, n, g.data_ptr(), ws.data_ptr(), nbytes, sp()))
+        ref = a.double().T @ a.double()
+        assert float((g - ref).abs().max()) <= 1e-13 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape,chi,mode", [((32, 32, 16, 24), 20, "Std"), ((64, 64, 64), 32, "Std"),
+                                            ((32, 32, 16, 24), 16, "DCT"), ((48, 40, 36), 12, "Std")], ids=str)
+def test_bf16_storage_matches_oracle_on_bf16_rounded_input(shape, chi, mode):
+    """dtype=torch.bfloat16: bf16 volume, bf16 carried matrices and cores, bf16 chain; against the fp64 oracle on
+    the same bf16-rounded values.  Bonds are equal (the cap binds), everything else within BF16_TOL."""
+    xb = torch.from_numpy(synthetic_mri(shape, seed=5)).to(DEV).to(torch.bfloat16)
+    obj = NDMPS.from_tensor(xb, max_bond=chi, mode=mode, dtype=torch.bfloat16)
+    ref = OracleNDMPS.from_tensor(xb.float().cpu().numpy(), max_bond=chi, mode=mode)
+    assert all(c.dtype == torch.bfloat16 for c in obj.mps.cores)
+    assert obj.bond_sizes() == ref.bond_sizes()
+    rr = ref.to_tensor()
+    rec = obj.to_tensor(as_torch=True)
+    assert rec.dtype == (torch.bfloat16 if mode == "Std" else torch.float32) and tuple(rec.shape) == shape
+    rel = float((rec.double().cpu() - torch.from_numpy(rr)).norm() / np.linalg.norm(rr))
+    assert rel <= BF16_TOL, rel
+    x64 = xb.double().cpu().numpy()
+    assert abs(compute_ssim_by_dim(x64, rec.double().cpu().numpy()) - compute_ssim_by_dim(x64, rr)) <= BF16_TOL
+    assert math.isclose(obj.norm_value, ref.norm_value, rel_tol=BF16_TOL)
+    # the rest of the class surface works on bf16 cores (fp32 copies of the small cores where a kernel is fp32)
+    assert math.isclose(obj.mps @ obj.mps, obj.norm_value ** 2, rel_tol=BF16_TOL)
+    assert 0 < obj.compression_ratio_on_disk(np.uint16) < 1
+    obj.compress(0.05)
+    assert all(c.dtype == torch.bfloat16 for c in obj.mps.cores)
+    assert obj.to_tensor().shape == shape
+
+
+def test_config5_full_size_bf16_storage_chi128_properties():
+    """BASELINE configs[4] as stated: 128x128x64x256 bf16, chi = 128, one GPU.  Size-independent properties
+    of the truncation (orthogonal projection: ||x||^2 = ||rec||^2 + ||x - rec||^2, <x - rec, rec> = 0) within
+    BF16_TOL, bonds and element count of SURVEY's table, bf16 cores and bf16 reconstruction."""
+    g = torch.Generator(device=DEV).manual_seed(7)
+    ax = [torch.linspace(-1, 1, n, device=DEV) for n in (128, 128, 64)]
+    vol = torch.zeros((128, 128, 64), device=DEV)
+    for c, w_, a in ((0.2, 0.3, 1.0), (-0.4, 0.15, 0.7), (0.5, 0.5, 0.4)):
+        vol += a * (torch.exp(-0.5 * ((ax[0] - c) / w_) ** 2)[:, None, None]
+                    * torch.exp(-0.5 * ((ax[1] + c) / w_) ** 2)[None, :, None]
+                    * torch.exp(-0.5 * (ax[2] / (2 * w_)) ** 2)[None, None, :])
+    tt = torch.linspace(0, 1, 256, device=DEV)
+    x = vol[..., None] * (1.0 + 0.25 * torch.sin(2 * math.pi * 2.0 * tt))
+    x = (x + 0.01 * torch.randn(x.shape, device=DEV, generator=g)).float()
+    x -= x.min()
+    x /= x.max()
+    xb = x.to(torch.bfloat16)
+    del x, vol
+    obj = NDMPS.from_tensor(xb, max_bond=128, dtype=torch.bfloat16)
+    assert obj.bond_sizes() == [64, 128, 128, 128, 32]
+    assert obj.number_elements_in_MPS() == 857088  # SURVEY 8 table
+    assert all(c.dtype == torch.bfloat16 for c in obj.mps.cores)
+    rec = obj.to_tensor(as_torch=True)
+    assert rec.dtype == torch.bfloat16
+    err = _projection_checks(xb.float(), obj, rec.float(), tol=BF16_TOL)
+    assert err < 1e-2
+    del rec, obj, xb
+    torch.cuda.empty_cache()
 
 
 def test_reference_flow_exact_then_compress_64_and_128_cubed():

@@ -1,0 +1,28 @@
+"""BASELINE configs[4]: 128x128x64x256, chi = 128, fp32 vs bf16 storage: encode + reconstruct time on one GPU."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imgcompressionmps_amd import NDMPS  # noqa: E402
+
+g = torch.Generator(device="cuda").manual_seed(7)
+x = torch.rand((128, 128, 64), device="cuda", generator=g)[..., None] * (1.0 + 0.25 * torch.sin(torch.linspace(0, 12.6, 256, device="cuda")))
+x = x + 0.01 * torch.randn(x.shape, device="cuda", generator=g)
+for dt in (torch.float32, torch.bfloat16):
+    xi = x.to(dt)
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        obj = NDMPS.from_tensor(xi, max_bond=128, dtype=dt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rec = obj.to_tensor(as_torch=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    n = x.numel()
+    print(f"{dt}: encode {1e3 * (t1 - t0):.1f} ms, reconstruct {1e3 * (t2 - t1):.1f} ms, {n / (t2 - t0) / 1e6:.0f} Mvoxels/s, "
+          f"bonds {obj.bond_sizes()}, rel err {float((rec.float() - xi.float()).norm() / xi.float().norm()):.3e}")
+    del obj, rec, xi
