@@ -26,6 +26,8 @@ SIGNATURES = {
     "ndmps_device_count": (C.c_int, []),
     "ndmps_streams_create": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(C.c_int)]),
     "ndmps_streams_destroy": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "ndmps_profile_enable": (C.c_int, [C.c_int]),
+    "ndmps_profile_collect": (C.c_int, [C.c_int, p_f64, p_i64, p_i64]),
     "ndmps_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, p_i64, C.c_int, p_i64]),
     "ndmps_plan_destroy": (C.c_int, [vp]),
     "ndmps_plan_numel": (i64, [vp]),

@@ -240,6 +240,32 @@ def _dist():
     return dist
 
 
+def broadcast_job(job=None, src: int = 0, group=None, device=None):
+    """Rank ``src`` sends the job descriptor (a JSON-serialisable dict: shape, chi, mode, batch, seeds, ...)
+    to every rank; returns the dict on all ranks.  Two broadcasts (length, payload) of tensors that live on
+    ``device`` (a HIP device for the nccl = RCCL backend, CPU for gloo).  This is the only collective a
+    sharded run needs before it starts; the data path has none."""
+    import json
+
+    import torch
+
+    dist = _dist()
+    rank = dist.get_rank(group)
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    if rank == src:
+        if job is None:
+            raise ValueError("the source rank must provide the job descriptor")
+        payload = torch.tensor(list(json.dumps(job, sort_keys=True).encode("utf-8")), dtype=torch.uint8, device=dev)
+        length = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+    else:
+        length = torch.zeros(1, dtype=torch.int64, device=dev)
+    dist.broadcast(length, src=src, group=group)
+    if rank != src:
+        payload = torch.zeros(int(length.item()), dtype=torch.uint8, device=dev)
+    dist.broadcast(payload, src=src, group=group)
+    return json.loads(bytes(payload.cpu().tolist()).decode("utf-8"))
+
+
 def pack_cores(core_tensors: Sequence):
     """Flatten a list of core tensors into (flat fp32 tensor, int64 shape table (n, 3))."""
     import torch

@@ -61,4 +61,9 @@ static inline int64_t arena_bytes(int64_t used, int64_t elem, int64_t count) {
 
 constexpr int kNumCU = 256;  // MI355X
 
+// launch spans for bench.py's roofline (util.hip); slot ids
+constexpr int kSpanTridiagColumns = 1;
+void* span_begin(hipStream_t s);
+void span_end(void* begin, hipStream_t s, int slot, int64_t launches, int64_t bytes);
+
 }  // namespace ndmps

@@ -1113,7 +1113,15 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
              : n_max <= 1024 ? trd_column_kernel<4, 32>
              : n_max <= 2048 ? trd_column_kernel<8, 32>
                              : trd_column_kernel<16, 32>;
-  for (int j = 0; j < n_max - kTail; ++j) hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
+  void* span = ndmps::span_begin(s);
+  int64_t span_bytes = 0;  // algorithmic: every trailing element read once and written once per column
+  for (int j = 0; j < n_max - kTail; ++j) {
+    hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
+    if (span)
+      for (int b = 0; b < batch; ++b)
+        if (j < h_n[b] - kTail) span_bytes += 2 * 8 * (h_n[b] - j - 1) * (h_n[b] - j - 1);
+  }
+  ndmps::span_end(span, s, ndmps::kSpanTridiagColumns, std::max<int64_t>(n_max - kTail, 0), span_bytes);
   hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
   const int kk = (int)std::min(k_max, n_max);
   hipLaunchKernelGGL(trd_bisect_kernel, dim3(ndmps::ceil_div(kk, 4), B), dim3(256),

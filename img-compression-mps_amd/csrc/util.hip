@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -99,5 +100,86 @@ extern "C" int ndmps_streams_destroy(int n, void* const* h_streams) {
   NDMPS_REQUIRE(n >= 0 && (n == 0 || h_streams), "bad stream list");
   for (int i = 0; i < n; ++i)
     if (h_streams[i]) NDMPS_CHECK_HIP(hipStreamDestroy((hipStream_t)h_streams[i]));
+  return NDMPS_OK;
+}
+
+// ---------------------------------------------------------------------------------- launch spans
+// bench.py's roofline needs the average duration of the dominant kernel's launches INSIDE the timed region,
+// on the stream they are launched on.  When enabled, a kernel sequence brackets itself with two HIP events
+// (ndmps::span_begin / span_end) and files them under a slot; ndmps_profile_collect() sums the elapsed
+// times.  Disabled (the default) nothing is recorded and the calls cost one relaxed load.
+namespace ndmps {
+namespace {
+struct Span {
+  hipEvent_t a, b;
+  int slot;
+  int64_t launches, bytes;
+};
+std::mutex g_span_mu;
+std::vector<Span> g_spans;
+std::vector<hipEvent_t> g_free_events;
+volatile int g_profile_on = 0;
+
+hipEvent_t take_event() {
+  if (!g_free_events.empty()) {
+    hipEvent_t e = g_free_events.back();
+    g_free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+void* span_begin(hipStream_t s) {
+  if (!g_profile_on) return nullptr;
+  std::lock_guard<std::mutex> lock(g_span_mu);
+  hipEvent_t e = take_event();
+  if (e && hipEventRecord(e, s) != hipSuccess) e = nullptr;
+  return e;
+}
+
+void span_end(void* begin, hipStream_t s, int slot, int64_t launches, int64_t bytes) {
+  if (!begin) return;
+  std::lock_guard<std::mutex> lock(g_span_mu);
+  hipEvent_t e = take_event();
+  if (!e || hipEventRecord(e, s) != hipSuccess) return;
+  g_spans.push_back(Span{(hipEvent_t)begin, e, slot, launches, bytes});
+}
+}  // namespace ndmps
+
+extern "C" int ndmps_profile_enable(int on) {
+  ndmps::g_profile_on = on ? 1 : 0;
+  return NDMPS_OK;
+}
+
+// Sums (and clears) the spans of `slot` recorded so far: total device milliseconds between their events,
+// kernel launches and algorithmic bytes they covered.  Synchronises on the recorded events.
+extern "C" int ndmps_profile_collect(int slot, double* h_ms, int64_t* h_launches, int64_t* h_bytes) {
+  using namespace ndmps;
+  NDMPS_REQUIRE(h_ms && h_launches && h_bytes, "NULL profile output");
+  std::lock_guard<std::mutex> lock(g_span_mu);
+  double ms = 0.0;
+  int64_t launches = 0, bytes = 0;
+  std::vector<Span> keep;
+  for (const Span& sp : g_spans) {
+    if (sp.slot != slot) {
+      keep.push_back(sp);
+      continue;
+    }
+    float t = 0.f;
+    NDMPS_CHECK_HIP(hipEventSynchronize(sp.b));
+    NDMPS_CHECK_HIP(hipEventElapsedTime(&t, sp.a, sp.b));
+    ms += t;
+    launches += sp.launches;
+    bytes += sp.bytes;
+    g_free_events.push_back(sp.a);
+    g_free_events.push_back(sp.b);
+  }
+  g_spans.swap(keep);
+  *h_ms = ms;
+  *h_launches = launches;
+  *h_bytes = bytes;
   return NDMPS_OK;
 }

@@ -49,6 +49,12 @@ int ndmps_device_count(void);
 int ndmps_streams_create(int n, void** h_streams, int* n_independent);
 int ndmps_streams_destroy(int n, void* const* h_streams);
 
+/* Launch spans for the roofline of bench.py: when enabled, the column launches of the direct eigen-solver
+ * (slot 1) bracket themselves with HIP events on their own stream; collect sums device ms, launches and
+ * algorithmic bytes of the spans recorded so far (and clears them).  No reference counterpart. */
+int ndmps_profile_enable(int on);
+int ndmps_profile_collect(int slot, double* h_ms, int64_t* h_launches, int64_t* h_bytes);
+
 /* ---------------------------------------------------------------------------------
  * Index permutation ("reshape stage").
  * Replaces: utils/core.py:6-35,129-168 (gen_encoding_map, never materialised here),

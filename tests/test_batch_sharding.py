@@ -78,3 +78,75 @@ def test_all_gather_world_size_2_gloo(n_volumes):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------- bench.py's rank / shard / MAX-reduce logic
+def _bench_worker(rank, world, port, q):
+    """What bench.py does around its step, with a stub step that sleeps (rank 1 sleeps longer): job descriptor
+    broadcast from rank 0, block-sharded distinct seeds, barrier-bracketed timing, MAX over ranks, whole-job
+    throughput.  gloo on CPU tensors; the step itself needs a GPU and is covered by the -m gpu tests."""
+    import time
+
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        args = bench.parse(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "8", "--size", "32"])
+        # rank 1 starts from a deliberately different descriptor: the broadcast must overwrite it
+        if rank != 0:
+            args.chi, args.batch = 7, 5
+        job = batch.broadcast_job(bench.job_descriptor(args, world) if rank == 0 else None, src=0)
+        seeds = bench.volume_seeds(job, rank)
+        calls = {"n": 0}
+
+        def step():
+            calls["n"] += 1
+            time.sleep(0.02 * (rank + 1))
+
+        def reduce_max(v):
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        marks = []
+        elapsed = bench.timed_steps(step, args.steps, args.warmup, dist.barrier, reduce_max,
+                                    after_warmup=lambda: marks.append(calls["n"]))
+        value = bench.throughput(job, 32 ** 3, args.steps, elapsed)
+        q.put((rank, job, seeds, calls["n"], marks, elapsed, value))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_rank_shard_and_max_reduce_logic_world_size_2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, job0, seeds0, n0, marks0, el0, v0), (_, job1, seeds1, n1, marks1, el1, v1) = results
+    assert job0 == job1 and job0["chi"] == 64 and job0["batch_per_gpu"] == 8 and job0["n_volumes"] == 16
+    assert seeds0 == list(range(2025, 2033)) and seeds1 == list(range(2033, 2041))  # distinct, contiguous blocks
+    assert n0 == n1 == 4 and marks0 == marks1 == [1]  # 1 warm-up + exactly 3 timed steps
+    assert el0 == el1 and el0 >= 3 * 0.04  # MAX over ranks: the slower rank (2 x 20 ms per step) sets it
+    assert v0 == v1 == pytest.approx(2 * 8 * 32 ** 3 * 3 / el0 / 1e6)
+
+
+def test_bench_default_job_is_baselines_batch_of_64_distinct_seeds():
+    import bench
+
+    args = bench.parse([])
+    job = bench.job_descriptor(args, 1)
+    assert (args.gpus, job["size"], job["chi"], job["batch_per_gpu"]) == (1, 256, 64, 64)
+    assert bench.volume_seeds(job, 0) == list(range(2025, 2089))  # SURVEY 8d: seeds 2025 .. 2088
+    job8 = bench.job_descriptor(bench.parse(["--gpus", "8", "--batch", "8"]), 8)
+    owned = [bench.volume_seeds(job8, r) for r in range(8)]
+    assert sum(owned, []) == list(range(2025, 2089)) and all(len(o) == 8 for o in owned)
