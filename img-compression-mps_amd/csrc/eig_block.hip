@@ -40,19 +40,14 @@ namespace {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// Block size BS (template parameter of the step kernel): 16 = 256 threads and four 32x32 LDS tiles
-// (33 KB, 4 workgroups per CU).  BS = 32 (1024 threads, four 64x64 tiles = 133 KB) halves the outer
-// steps per sweep and with them the trips of G and V through the cache hierarchy, but measured
-// SLOWER on MI355X (256^3, chi 64: single volume 36 vs 26 ms, group of 8: 55 vs 45 ms): the diag role's
-// inner step moves 4x the LDS bytes per barrier (1.15 vs 0.55 us) and one workgroup per CU starves the
-// apply role.  It stays selectable with NDMPS_EIG_BLOCK=32 (n >= 256) for experiments and is
-// covered by a test.
+// Block size 16: 256 threads and four 32x32 LDS tiles (33 KB, 4 workgroups per CU).  A 32-wide variant (1024
+// threads, 64x64 tiles) halves the outer steps per sweep but measured slower on MI355X (round 1: single
+// volume 36 vs 26 ms) -- the diag role's inner step moves 4x the LDS bytes per barrier and one workgroup per
+// CU starves the apply role -- and was removed.
 constexpr int kMaxSweepsBlock = 40;
-inline int block_size_for(int64_t n_max) {
-  const char* e = getenv("NDMPS_EIG_BLOCK");
-  return (e && atoi(e) == 32 && n_max >= 256) ? 32 : 16;
-}
-inline int tiles_per_wg(int bs) { return bs == 32 ? 4 : 8; }  // column pairs streamed by one apply workgroup
+constexpr int BS = 16;
+inline int block_size_for(int64_t) { return BS; }
+inline int tiles_per_wg(int) { return 8; }  // column pairs streamed by one apply workgroup (V strips)
 
 // one entry per matrix of the batch (device array); blockIdx.y selects it in every kernel
 struct BatchDesc {
@@ -173,11 +168,10 @@ __device__ __forceinline__ int block_sum_int(int v, int* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// offset of G(r, c) in a work matrix.  Block size 16: every 16x16 block is contiguous (2 KB), so an MFMA
-// operand fetch of the register apply path is one 512-byte run and a step streams whole blocks instead
-// of 128-byte pieces of 4 KB-strided rows.  Block size 32 (experimental path): plain row-major.
-__device__ __forceinline__ int64_t g_off(int bs, int np, int64_t r, int64_t c) {
-  if (bs != 16) return r * np + c;
+// offset of G(r, c) in a work matrix: every 16x16 block is contiguous (2 KB), so an MFMA operand fetch of the
+// register apply path is one 512-byte run and a step streams whole blocks instead of 128-byte pieces of
+// 4 KB-strided rows.
+__device__ __forceinline__ int64_t g_off(int, int np, int64_t r, int64_t c) {
   return (((r >> 4) * (np >> 4) + (c >> 4)) << 8) + ((r & 15) << 4) + (c & 15);
 }
 
@@ -254,7 +248,7 @@ __global__ void blk_check_kernel(BatchDesc* __restrict__ desc, int batch, int sw
 // ---------------------------------------------------------------------------- step kernel
 // C(PS x PS) = op(A) * B in LDS, f64 MFMA; (PS/16)^2 waves, one 16x16 output tile each.
 // TRANS_A: A given as (k, i) (i.e. C = A^T B).
-template <int BS, bool TRANS_A>
+template <bool TRANS_A>
 __device__ __forceinline__ void lds_gemm(const double (*A)[2 * BS + 1], const double (*B)[2 * BS + 1],
                                          double (*Cout)[2 * BS + 1], int wave, int lane) {
   constexpr int PS = 2 * BS, TPR = PS / 16;
@@ -302,7 +296,6 @@ __device__ __forceinline__ void locate_block(int x, int t, int nb, int& k, int& 
   pos = x < partner ? 0 : 1;
 }
 
-template <int BS>
 __device__ __forceinline__ int64_t pair_index(int e, int lo, int hi) {  // e in [0, 2 BS)
   return e < BS ? (int64_t)lo * BS + e : (int64_t)hi * BS + e - BS;
 }
@@ -314,7 +307,6 @@ __device__ __forceinline__ int64_t pair_index(int e, int lo, int hi) {  // e in 
 //   first    : diag role reads the initial matrix directly (nothing to apply yet)
 //   solve    : single block pair = whole matrix, iterate to convergence in LDS
 //   in, out  : G ping-pong indices;  q_cur: parity of the Q / D buffers being applied
-template <int BS>
 __global__ void __launch_bounds__(BS * BS)
 blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_next, int full_next,
                 int sweep_next, int first, int solve, int in, int q_cur, int kTilesPerWg, int gstep) {
@@ -350,11 +342,10 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     // ================================================================== apply role (step t)
     // One workgroup = one row pair (or one 32-row strip of V) x kTilesPerWg column pairs: Q_A is
     // loaded once, tiles stream through LDS; 16-byte global accesses (thread = row, 2-double segment).
-    double* Gout = w.G[in ^ 1] + mat;
     double* V = w.V + mat;
     const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
     int bid = blockIdx.x - n_diag;
-    if constexpr (BS == 16) {
+    {
       // G tiles, register-only: one WAVE = one upper tile (pa < pb), no LDS and no barrier.  With
       // R = Q_A^T T Q_B, the wave computes, for each 16-column half h of pair A,
       // R^T[:, h] = Q_B^T (T^T Q_A[:, h]): the accumulator of the first product (row 4r + lk, column li)
@@ -375,7 +366,7 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const int e = 2 * lane + 128 * q;
-            *reinterpret_cast<double2*>(Gout + g_off(BS, np, pair_index<BS>(e / PS, lo, hi), pair_index<BS>(e % PS, lo, hi))) =
+            *reinterpret_cast<double2*>(Gout + g_off(BS, np, pair_index(e / PS, lo, hi), pair_index(e % PS, lo, hi))) =
                 *reinterpret_cast<const double2*>(dsrc + e);
           }
           return;
@@ -456,40 +447,18 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       }
       bid -= g_wgs;
     }
-    const bool is_g = BS != 16 && bid < half * chunks;
-    int pa = 0, strip = 0, chunk;
-    if (is_g) {
-      pa = bid / chunks;
-      chunk = bid % chunks;
-    } else {
-      if (BS != 16) bid -= half * chunks;
-      strip = bid / chunks;
-      chunk = bid % chunks;
-    }
-    int lo_a = 0, hi_a = 0;
-    if (is_g) pair_blocks(pa, t, nb, lo_a, hi_a);
+    // V strips (in-loop eigenvector update of the non-history mode): one workgroup = one 32-row strip of V x
+    // kTilesPerWg column pairs, tiles stream through LDS; 16-byte global accesses (thread = row, 2-double segment)
+    const int strip = bid / chunks, chunk = bid % chunks;
     const int row = tid / (BS / 2), c0 = (tid % (BS / 2)) * 2;  // this thread's row and column offset inside a block
-    const int64_t grow = is_g ? pair_index<BS>(row, lo_a, hi_a) : (int64_t)strip * PS + row;
-    const double* Min = is_g ? Gin : V;
-    double* Mout = is_g ? Gout : V;
-    if (is_g) {
-      const double2 a0 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pa * PS * PS + row * PS + c0);
-      const double2 a1 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pa * PS * PS + row * PS + BS + c0);
-      QA[row][c0] = a0.x;
-      QA[row][c0 + 1] = a0.y;
-      QA[row][BS + c0] = a1.x;
-      QA[row][BS + c0 + 1] = a1.y;
-    }
+    const int64_t grow = (int64_t)strip * PS + row;
     // software pipeline: the operands of tile j+1 are fetched into registers while tile j is in LDS
     double2 t0, t1, q0, q1;
-    // G is symmetric: only tiles with pb > pa are computed, each result is written to (pa, pb) and,
-    // transposed, to (pb, pa) -- half the reads and MFMAs, and G stays exactly symmetric
     auto fetch = [&](int pb_) {
       int lo_b_, hi_b_;
       pair_blocks(pb_, t, nb, lo_b_, hi_b_);
-      if (is_g && pb_ <= pa) return;  // diagonal tile (copied) or lower triangle (mirrored)
-      t0 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)lo_b_ * BS + c0);
-      t1 = *reinterpret_cast<const double2*>(Min + grow * np + (int64_t)hi_b_ * BS + c0);
+      t0 = *reinterpret_cast<const double2*>(V + grow * np + (int64_t)lo_b_ * BS + c0);
+      t1 = *reinterpret_cast<const double2*>(V + grow * np + (int64_t)hi_b_ * BS + c0);
       q0 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb_ * PS * PS + row * PS + c0);
       q1 = *reinterpret_cast<const double2*>(Qcur + (int64_t)pb_ * PS * PS + row * PS + BS + c0);
     };
@@ -500,19 +469,8 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       if (pb >= half) break;
       int lo_b, hi_b;
       pair_blocks(pb, t, nb, lo_b, hi_b);
-      double* o0 = Mout + grow * np + (int64_t)lo_b * BS + c0;
-      double* o1 = Mout + grow * np + (int64_t)hi_b * BS + c0;
-      if (is_g && pa == pb) {  // diagonal tile: prepared (already rotated) by the diag role
-        const double* dsrc = Dcur + (int64_t)pa * PS * PS + row * PS;
-        *reinterpret_cast<double2*>(o0) = *reinterpret_cast<const double2*>(dsrc + c0);
-        *reinterpret_cast<double2*>(o1) = *reinterpret_cast<const double2*>(dsrc + BS + c0);
-        if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);
-        continue;
-      }
-      if (is_g && pb < pa) {  // written by the workgroup that owns (pb, pa)
-        if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);
-        continue;
-      }
+      double* o0 = V + grow * np + (int64_t)lo_b * BS + c0;
+      double* o1 = V + grow * np + (int64_t)hi_b * BS + c0;
       __syncthreads();  // the previous tile's readers of T / QB / X are done
       T[row][c0] = t0.x;
       T[row][c0 + 1] = t0.y;
@@ -522,25 +480,12 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       QB[row][c0 + 1] = q0.y;
       QB[row][BS + c0] = q1.x;
       QB[row][BS + c0 + 1] = q1.y;
-      if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);  // in flight during the two GEMMs
+      if (j + 1 < kTilesPerWg && pb + 1 < half) fetch(pb + 1);  // in flight during the GEMM
       __syncthreads();
-      lds_gemm<BS, false>(T, QB, X, wave, lane);  // X = T Q_B
+      lds_gemm<false>(T, QB, X, wave, lane);  // X = T Q_B
       __syncthreads();
-      double (*res)[LD] = X;
-      if (is_g) {
-        lds_gemm<BS, true>(QA, X, T, wave, lane);  // T = Q_A^T X
-        __syncthreads();
-        res = T;
-      }
-      *reinterpret_cast<double2*>(o0) = make_double2(res[row][c0], res[row][c0 + 1]);
-      *reinterpret_cast<double2*>(o1) = make_double2(res[row][BS + c0], res[row][BS + c0 + 1]);
-      if (is_g) {  // mirror: tile (pb, pa) = res^T (LDS column reads, odd row stride: conflict-free)
-        const int64_t trow = pair_index<BS>(row, lo_b, hi_b);
-        *reinterpret_cast<double2*>(Mout + trow * np + (int64_t)lo_a * BS + c0) =
-            make_double2(res[c0][row], res[c0 + 1][row]);
-        *reinterpret_cast<double2*>(Mout + trow * np + (int64_t)hi_a * BS + c0) =
-            make_double2(res[BS + c0][row], res[BS + c0 + 1][row]);
-      }
+      *reinterpret_cast<double2*>(o0) = make_double2(X[row][c0], X[row][c0 + 1]);
+      *reinterpret_cast<double2*>(o1) = make_double2(X[row][BS + c0], X[row][BS + c0 + 1]);
     }
     return;
   }
@@ -559,7 +504,7 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
   if (first) {
     for (int e = tid; e < PS * PS; e += NT) {
       const int a = e / PS, b = e % PS;
-      const int64_t ga = pair_index<BS>(a, lo, hi), gb = pair_index<BS>(b, lo, hi);
+      const int64_t ga = pair_index(a, lo, hi), gb = pair_index(b, lo, hi);
       S0[a][b] = 0.5 * (Gin[g_off(BS, np, ga, gb)] + Gin[g_off(BS, np, gb, ga)]);
       Q[a][b] = (a == b) ? 1.0 : 0.0;
     }
@@ -579,8 +524,8 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
     const double d_hi = Dcur[(int64_t)kb * PS * PS + (pb * BS + r16) * PS + pb * BS + c16];
     for (int e = tid; e < PS * PS; e += NT) {
       const int a = e / PS, b = e % PS;
-      int64_t ga = pair_index<BS>(a, a_lo, a_hi), gb = pair_index<BS>(b, b_lo, b_hi);
-      if (BS == 16 && ga / BS > gb / BS) {  // block-upper storage: read the mirror image
+      int64_t ga = pair_index(a, a_lo, a_hi), gb = pair_index(b, b_lo, b_hi);
+      if (ga / BS > gb / BS) {  // block-upper storage: read the mirror image
         const int64_t tmp = ga;
         ga = gb;
         gb = tmp;
@@ -590,9 +535,9 @@ blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_n
       QB[a][b] = Qcur[(int64_t)kb * PS * PS + e];
     }
     __syncthreads();
-    lds_gemm<BS, false>(T, QB, X, wave, lane);  // X = T Q_B
+    lds_gemm<false>(T, QB, X, wave, lane);  // X = T Q_B
     __syncthreads();
-    lds_gemm<BS, true>(QA, X, T, wave, lane);  // T = Q_A^T X  (tile (ka, kb) after step t)
+    lds_gemm<true>(QA, X, T, wave, lane);  // T = Q_A^T X  (tile (ka, kb) after step t)
     __syncthreads();
     {
       const double v = T[pa * BS + r16][pb * BS + c16];  // cross block (lo, hi)
@@ -930,23 +875,28 @@ BlockLayout block_layout(int64_t n_max, int64_t batch) {
 
 // Solver state between the two phases: values() iterates to convergence and delivers the sorted
 // eigenvalues; vectors(k) delivers the first k eigenvectors of every matrix.
-// per host thread: two pinned ints and two events for the pipelined convergence test of values()
+// Two pinned ints and two events for the pipelined convergence test of values().  They come from a process-wide
+// pool (one set per concurrently running solve and device, reused afterwards): per-thread storage leaked a
+// pinned allocation and two events for every worker thread a caller ever created.
 struct HostFlags {
   int* flags = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
   int device = -1;
 };
-inline HostFlags* host_flags() {
-  static thread_local HostFlags hf;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (hf.flags != nullptr && hf.device != dev) {  // events belong to a device
-    (void)hipEventDestroy(hf.ev[0]);
-    (void)hipEventDestroy(hf.ev[1]);
-    (void)hipHostFree(hf.flags);
-    hf = HostFlags();
-  }
-  if (hf.flags == nullptr) {
+class HostFlagsPool {
+ public:
+  HostFlags* acquire() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i]->device == dev) {
+          HostFlags* hf = free_[i];
+          free_.erase(free_.begin() + i);
+          return hf;
+        }
+    }
     int* p = nullptr;
     if (hipHostMalloc((void**)&p, 64, hipHostMallocPortable) != hipSuccess) return nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -955,12 +905,48 @@ inline HostFlags* host_flags() {
       (void)hipHostFree(p);
       return nullptr;
     }
-    hf.flags = p;
-    hf.ev[0] = e0;
-    hf.ev[1] = e1;
-    hf.device = dev;
+    HostFlags* hf = new HostFlags();
+    hf->flags = p;
+    hf->ev[0] = e0;
+    hf->ev[1] = e1;
+    hf->device = dev;
+    return hf;
   }
-  return &hf;
+  void release(HostFlags* hf) {
+    if (!hf) return;
+    std::lock_guard<std::mutex> lock(mu_);
+    free_.push_back(hf);
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<HostFlags*> free_;
+};
+inline HostFlagsPool& host_flags_pool() {
+  static HostFlagsPool* pool = new HostFlagsPool();  // never destroyed: no HIP calls at process exit
+  return *pool;
+}
+struct HostFlagsLease {
+  HostFlags* hf;
+  HostFlagsLease() : hf(host_flags_pool().acquire()) {}
+  ~HostFlagsLease() { host_flags_pool().release(hf); }
+};
+
+// kernels that need more than 64 KB of dynamic LDS are opted in once per DEVICE (function attributes are
+// per device: a process that moves to a second GPU must opt in there too)
+inline int blk_opt_in() {
+  static std::mutex mu;
+  static bool done[64] = {};
+  int dev = 0;
+  NDMPS_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev < 0 || dev >= 64 || done[dev]) return NDMPS_OK;
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel<4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (kHistMaxNp * 17 + 4 * 32 * 33) * 8));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel<8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBackacc8MaxLds));
+  done[dev] = true;
+  return NDMPS_OK;
 }
 
 struct BatchedJacobi {
@@ -1010,26 +996,10 @@ struct BatchedJacobi {
 
   int values() {
     const int np = w.np, nb = w.nb, half = nb / 2;
-    const int BS = w.bs, PS = 2 * BS, kTilesPerWg = tiles_per_wg(BS);
+    const int PS = 2 * BS, kTilesPerWg = tiles_per_wg(BS);
     const size_t lds_bytes = (size_t)4 * PS * (PS + 1) * sizeof(double);
-    // > 64 KB of dynamic LDS needs an explicit opt-in; once per process, and concurrent groups make
-    // their first call from several host threads at the same moment
-    static std::once_flag attr_once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(attr_once, [] {
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_step_kernel<32>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 65 * 8);
-      if (attr_err == hipSuccess)
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel<4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (kHistMaxNp * 17 + 4 * 32 * 33) * 8);
-      if (attr_err == hipSuccess)
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&blk_backacc_kernel<8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBackacc8MaxLds);
-    });
-    NDMPS_CHECK_HIP(attr_err);
+    NDMPS_TRY(blk_opt_in());
     const unsigned B = (unsigned)batch;
-    // one launch of the step kernel (both block sizes share the argument list)
     // NDMPS_EIG_DEBUG_ROLE = 1 / 2: launch only the diag / apply role (timing experiments; results are wrong)
     static const int debug_role = [] {
       const int v = getenv("NDMPS_EIG_DEBUG_ROLE") ? atoi(getenv("NDMPS_EIG_DEBUG_ROLE")) : 0;
@@ -1040,12 +1010,8 @@ struct BatchedJacobi {
                     int in, int q_cur, int gstep) {
       if (debug_role == 1 && n_diag > 0) gx = n_diag;
       if (debug_role == 2 && (int)gx > n_diag && n_diag > 0) { gx -= n_diag; n_diag = 0; }
-      if (BS == 32)
-        hipLaunchKernelGGL(blk_step_kernel<32>, dim3(gx, B), dim3(1024), lds_bytes, s, desc, w, n_diag, t, t_next,
-                           full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg, gstep);
-      else
-        hipLaunchKernelGGL(blk_step_kernel<16>, dim3(gx, B), dim3(256), lds_bytes, s, desc, w, n_diag, t, t_next,
-                           full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg, gstep);
+      hipLaunchKernelGGL(blk_step_kernel, dim3(gx, B), dim3(256), lds_bytes, s, desc, w, n_diag, t, t_next,
+                         full_next, sweep_next, first, solve, in, q_cur, kTilesPerWg, gstep);
     };
     const int fill_grid = (int)std::min<int64_t>(ndmps::ceil_div((int64_t)np * np, 256), 1024);
     hipLaunchKernelGGL(blk_scale_kernel, dim3(1, B), dim3(256), 0, s, desc);
@@ -1058,8 +1024,7 @@ struct BatchedJacobi {
     sweeps = 0;
     const int chunks = (half + kTilesPerWg - 1) / kTilesPerWg;
     // history mode: the apply role has no V tiles
-    const int n_apply = (BS == 16 ? (half + half * (half - 1) / 2 + 3) / 4 : half * chunks) +
-                        (w.hist_mode ? 0 : (np / PS) * chunks);
+    const int n_apply = (half + half * (half - 1) / 2 + 3) / 4 + (w.hist_mode ? 0 : (np / PS) * chunks);
     const int steps = nb - 1;  // outer steps per sweep
     if (nb == 2) {
       // every matrix is one block pair: solved in LDS by the diag role, then applied once
@@ -1078,7 +1043,8 @@ struct BatchedJacobi {
       // the stream never drains while the host looks at it (the round trip cost ~30 us per sweep, ~75
       // sweeps per 256^3 volume).  If sweep k turns out to have converged everything, the launches of
       // sweep k+1 find every matrix marked done by sweep k's check kernel and return at once.
-      HostFlags* hf = host_flags();
+      HostFlagsLease lease;
+      HostFlags* hf = lease.hf;
       NDMPS_REQUIRE(hf != nullptr, "pinned flag buffer / events could not be created");
       int enqueued = 0, verified = 0;
       while (true) {
@@ -1103,6 +1069,9 @@ struct BatchedJacobi {
         }
       }
       sweeps = verified;
+      // the copy of the last enqueued sweep's flag may still be in flight: let it land before the pinned
+      // buffer goes back to the pool (that sweep's launches were no-ops)
+      NDMPS_CHECK_HIP(hipEventSynchronize(hf->ev[(enqueued - 1) & 1]));
     }
     if (remaining != 0) {
       ndmps::set_error("block Jacobi did not converge in %d sweeps (n=%lld, %d of %d matrices left)",
