@@ -57,6 +57,10 @@ SIGNATURES = {
     "ndmps_convert_f32_to_bf16": (C.c_int, [vp, i64, vp, vp]),
     "ndmps_tt_sweep_batched_bf16": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
                                               C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, i64, vp]),
+    "ndmps_chain_tail_columns": (i64, [C.c_int, p_i64]),
+    "ndmps_plan_split_offsets": (C.c_int, [vp, i64, p_i64, p_i64]),
+    "ndmps_chain_contract_scatter_f32": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), vp, vp, vp, vp, i64, vp, i64, vp]),
+    "ndmps_sgemm_indexed": (C.c_int, [i64, i64, i64, vp, i64, vp, vp, C.c_int, vp, i64, vp, i64, vp, vp, vp]),
     "ndmps_chain_contract_bf16": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), vp, vp, i64, vp]),
     "ndmps_syevj_workspace_bytes": (i64, [i64]),
     "ndmps_syevj_f64": (C.c_int, [vp, i64, vp, vp, vp, i64, p_int, vp]),

@@ -248,6 +248,21 @@ class DeviceMPS:
         _lib.check(fn(L, dims, bonds, self._core_ptrs(), out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr()))
         return out
 
+    def to_volume(self, out, n_tail, tables):
+        """Chain contraction straight into the C-order volume ``out`` (fp32 cores): the last product scatters
+        through the inverse permutation (``tables`` = _Plan.split_tables(n_tail, device))."""
+        torch = _torch()
+        lib = _lib.load()
+        L = len(self.cores)
+        dims, bonds = _lib.i64_array(self.dims), _lib.i64_array(self.bonds)
+        row_off, col_off, col_perm = tables
+        nbytes = lib.ndmps_chain_workspace_bytes(L, dims, bonds)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        _lib.check(lib.ndmps_chain_contract_scatter_f32(L, dims, bonds, self._core_ptrs(), out.data_ptr(),
+                                                        row_off.data_ptr(), col_off.data_ptr(), col_perm.data_ptr(),
+                                                        int(n_tail), ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        return out
+
     def compress_bond_(self, i, cutoff, max_bond=None):
         """tensor_compress_bond on bond (i-1, i) (core/ndmps.py:104-106); returns the spectrum.  bf16 cores
         are truncated in fp32 and stored back as bf16."""

@@ -103,6 +103,29 @@ class _Plan:
         self.handle = handle
         self.numel = int(np.prod(self.shape, dtype=np.int64))
 
+        self._split = {}
+
+    def split_tables(self, n_cols, device):
+        """Device tables for the site-order tensor viewed as (numel / n_cols) x n_cols: element (r, c) sits at
+        row_off[r] + col_off[c] of the C-order volume (offsets are additive over sites).  Returned with the
+        columns in memory order: (row_off, col_off ascending, col_perm = site-order column of the c-th smallest
+        offset), int64 / int64 / int32.  Built once per (n_cols, device), with synchronous uploads."""
+        torch = _torch()
+        key = (int(n_cols), str(device))
+        with _CACHE_LOCK:
+            if key not in self._split:
+                rows = self.numel // int(n_cols)
+                row_off = np.empty(rows, dtype=np.int64)
+                col_off = np.empty(int(n_cols), dtype=np.int64)
+                _lib.check(_lib.load().ndmps_plan_split_offsets(
+                    self.handle, int(n_cols), row_off.ctypes.data_as(_lib.p_i64), col_off.ctypes.data_as(_lib.p_i64)))
+                perm = np.argsort(col_off, kind="stable")
+                self._split[key] = (torch.from_numpy(row_off).to(device),
+                                    torch.from_numpy(np.ascontiguousarray(col_off[perm])).to(device),
+                                    torch.from_numpy(perm.astype(np.int32)).to(device))
+                torch.cuda.synchronize(device)
+            return self._split[key]
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
@@ -399,12 +422,20 @@ class NDMPS:
         with torch.cuda.device(device):
             plan = _plan_for(self._shape, device.index or 0)
             stream = _lib.stream_ptr()
-            with _span("chain"):
-                dense = self.mps.to_dense()
-            out = torch.empty(self._shape, dtype=dense.dtype, device=device)
-            with _span("decode_permute"):
-                _lib.check(lib.ndmps_decode_permute(plan.handle, dense.data_ptr(), out.data_ptr(), dense.element_size(),
-                                                    stream))
+            dims = _lib.i64_array(self.mps.dims)
+            n_tail = lib.ndmps_chain_tail_columns(len(self.mps.dims), dims) if self.mps.dtype == torch.float32 else 0
+            if n_tail > 0:
+                # fp32: the inverse permutation rides on the last product of the chain; no site-order tensor
+                out = torch.empty(self._shape, dtype=torch.float32, device=device)
+                with _span("chain"):
+                    self.mps.to_volume(out, n_tail, plan.split_tables(n_tail, device))
+            else:
+                with _span("chain"):
+                    dense = self.mps.to_dense()
+                out = torch.empty(self._shape, dtype=dense.dtype, device=device)
+                with _span("decode_permute"):
+                    _lib.check(lib.ndmps_decode_permute(plan.handle, dense.data_ptr(), out.data_ptr(),
+                                                        dense.element_size(), stream))
             if self.mode == "DCT":
                 n = self._shape[-1]
                 out = out.to(torch.float32)  # the IDCT kernel is fp32 (bf16 storage: upcast copy)

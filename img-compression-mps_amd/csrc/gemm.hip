@@ -71,10 +71,22 @@ struct alignas(sizeof(T) * 4) Quad {
   T v[4];
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool VEC>
+// Optional table-driven addressing (IDX): element (m, k) of A at A[a_row[m] + a_col[k]], element (m, n) of C
+// at C[c_row[m] + c_col[n]]; a NULL pair means dense row-major for that operand.  This is how the index
+// permutation of the reshape stage rides on a product: the offset of a site-order element is additive over
+// sites (permute.hip), so for any split of the sites into a row part and a column part it is
+// RowOff[r] + ColOff[c].  With VEC, a_col must come in aligned runs of 4 consecutive offsets.
+struct GemmIndex {
+  const int64_t* a_row;
+  const int64_t* a_col;
+  const int64_t* c_row;
+  const int64_t* c_col;
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool VEC, bool IDX = false>
 __global__ void __launch_bounds__(256)
 gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
-            const T* __restrict__ B, int64_t ldb, T* __restrict__ C, int64_t ldc) {
+            const T* __restrict__ B, int64_t ldb, T* __restrict__ C, int64_t ldc, GemmIndex ix = GemmIndex()) {
   using MF = Mfma<T>;
   constexpr int BK = 16;
   constexpr int MT = MF::MT;
@@ -120,7 +132,10 @@ gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t ld
           if (k0 + k < K && m0 + m < M) q = *reinterpret_cast<const Quad<T>*>(A + (k0 + k) * lda + m0 + m);
         } else {
           const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
-          if (k0 + k < K && m0 + m < M) q = *reinterpret_cast<const Quad<T>*>(A + (m0 + m) * lda + k0 + k);
+          if (k0 + k < K && m0 + m < M) {
+            if (IDX && ix.a_row) q = *reinterpret_cast<const Quad<T>*>(A + ix.a_row[m0 + m] + ix.a_col[k0 + k]);
+            else q = *reinterpret_cast<const Quad<T>*>(A + (m0 + m) * lda + k0 + k);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) ra[4 * i + j] = q.v[j];
@@ -138,7 +153,8 @@ gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t ld
           k = e % BK;
         }
         const int64_t gk = k0 + k, gm = m0 + m;
-        ra[i] = (gk < K && gm < M) ? (TA ? A[gk * lda + gm] : A[gm * lda + gk]) : (T)0;
+        if (IDX && ix.a_row) ra[i] = (gk < K && gm < M) ? A[ix.a_row[gm] + ix.a_col[gk]] : (T)0;
+        else ra[i] = (gk < K && gm < M) ? (TA ? A[gk * lda + gm] : A[gm * lda + gk]) : (T)0;
       }
     }
   };
@@ -258,7 +274,10 @@ gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t ld
 #pragma unroll
       for (int r = 0; r < MF::NACC; ++r) {
         const int64_t row = m0 + (wm * TM + i) * MT + MF::acc_row(r, lane);
-        if (row < M && col < N) C[row * ldc + col] = acc[i][j][r];
+        if (row < M && col < N) {
+          if (IDX && ix.c_row) C[ix.c_row[row] + ix.c_col[col]] = acc[i][j][r];
+          else C[row * ldc + col] = acc[i][j][r];
+        }
       }
     }
 }
@@ -670,6 +689,46 @@ extern "C" int ndmps_sgemm(int transA, int transB, int64_t m, int64_t n, int64_t
   if (n <= 64 || m <= 64)
     return launch_gemm<float, 64, 64, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
   return launch_gemm<float, 128, 128, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
+}
+
+// C = A B (no transposes) with table-driven addressing of A and / or C (see GemmIndex): the reshape stage fused
+// into a product of the sweep (A = the volume read through the permutation) or of the chain (C = the
+// reconstructed volume written through the inverse permutation).  a_vec4: every aligned group of four
+// consecutive k has consecutive offsets in d_a_col (16-byte loads allowed).
+extern "C" int ndmps_sgemm_indexed(int64_t m, int64_t n, int64_t k, const float* d_A, int64_t lda,
+                                   const int64_t* d_a_row, const int64_t* d_a_col, int a_vec4, const float* d_B,
+                                   int64_t ldb, float* d_C, int64_t ldc, const int64_t* d_c_row,
+                                   const int64_t* d_c_col, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(m >= 0 && n >= 0 && k >= 0 && d_A && d_B && d_C, "bad indexed GEMM argument");
+  NDMPS_REQUIRE((d_a_row == nullptr) == (d_a_col == nullptr) && (d_c_row == nullptr) == (d_c_col == nullptr),
+                "offset tables come in (row, column) pairs");
+  NDMPS_REQUIRE(ldb >= n && (d_a_row || lda >= k) && (d_c_row || ldc >= n), "leading dimension too small");
+  if (m == 0 || n == 0) return NDMPS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GemmIndex ix{d_a_row, d_a_col, d_c_row, d_c_col};
+  const uintptr_t al = 16;
+  const bool vec = ldb % 4 == 0 && k % 4 == 0 && n % 4 == 0 && (uintptr_t)d_A % al == 0 && (uintptr_t)d_B % al == 0 &&
+                   (d_a_row ? a_vec4 != 0 : lda % 4 == 0);
+  const dim3 block(256);
+  if (n <= 64 || m <= 64) {
+    const dim3 grid((unsigned)ndmps::ceil_div(m, 64), (unsigned)ndmps::ceil_div(n, 64));
+    if (vec)
+      hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 2, 2, false, false, true, true>), grid, block, 0, s, m, n, k, d_A,
+                         lda, d_B, ldb, d_C, ldc, ix);
+    else
+      hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 2, 2, false, false, false, true>), grid, block, 0, s, m, n, k, d_A,
+                         lda, d_B, ldb, d_C, ldc, ix);
+  } else {
+    const dim3 grid((unsigned)ndmps::ceil_div(m, 128), (unsigned)ndmps::ceil_div(n, 128));
+    if (vec)
+      hipLaunchKernelGGL((gemm_kernel<float, 128, 128, 2, 2, false, false, true, true>), grid, block, 0, s, m, n, k,
+                         d_A, lda, d_B, ldb, d_C, ldc, ix);
+    else
+      hipLaunchKernelGGL((gemm_kernel<float, 128, 128, 2, 2, false, false, false, true>), grid, block, 0, s, m, n, k,
+                         d_A, lda, d_B, ldb, d_C, ldc, ix);
+  }
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
 }
 
 extern "C" int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const double* d_A,

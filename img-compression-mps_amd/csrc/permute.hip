@@ -538,6 +538,34 @@ extern "C" int ndmps_plan_emulate(int ndim, const int64_t* h_shape, int L, const
   return plan.tiled;
 }
 
+// Source offsets of the site-order tensor viewed as a (numel / n_cols) x n_cols matrix: the offset of a
+// site-order element is additive over sites, so element (r, c) sits at h_row_off[r] + h_col_off[c] of the C-order
+// volume whenever n_cols is a product of trailing site dimensions.  Host tables (no GPU needed).
+extern "C" int ndmps_plan_split_offsets(const ndmps_plan_t* plan, int64_t n_cols, int64_t* h_row_off,
+                                        int64_t* h_col_off) {
+  NDMPS_REQUIRE(plan && h_row_off && h_col_off, "NULL argument");
+  const DevPlan& p = plan->dev;
+  NDMPS_REQUIRE(n_cols >= 1 && p.numel % n_cols == 0, "n_cols=%lld does not divide the tensor", (long long)n_cols);
+  const HostTables& h = plan->host;
+  auto source = [&](int64_t o) {
+    int64_t rem = o, off = 0;
+    for (int g = p.n_groups - 1; g >= 0; --g) {
+      off += h.group_tab[g][rem % p.group_size[g]];
+      rem /= p.group_size[g];
+    }
+    return off;
+  };
+  for (int64_t c = 0; c < n_cols; ++c) h_col_off[c] = source(c);
+  for (int64_t r = 0; r < p.numel / n_cols; ++r) h_row_off[r] = source(r * n_cols);
+  // additivity holds only for splits between sites: verify on a sample instead of trusting the caller
+  for (int64_t t = 0; t < 64; ++t) {
+    const int64_t r = (t * 7919) % (p.numel / n_cols), c = (t * 104729) % n_cols;
+    NDMPS_REQUIRE(source(r * n_cols + c) == h_row_off[r] + h_col_off[c],
+                  "n_cols=%lld is not a product of trailing site dimensions", (long long)n_cols);
+  }
+  return NDMPS_OK;
+}
+
 extern "C" int64_t ndmps_plan_numel(const ndmps_plan_t* plan) { return plan ? plan->dev.numel : -1; }
 extern "C" int ndmps_plan_is_tiled(const ndmps_plan_t* plan) { return plan ? plan->tiled : -1; }
 

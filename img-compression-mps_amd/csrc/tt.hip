@@ -779,9 +779,38 @@ extern "C" int64_t ndmps_chain_workspace_bytes(int L, const int64_t* h_dims, con
 }
 
 namespace {
+struct ChainScatter {          // inverse permutation in the epilogue of the last product (fp32 only)
+  const int64_t* row_off;      // [numel / n_cols] offset of tail-block r in the C-order volume
+  const int64_t* col_off;      // [n_cols] offsets inside a block, ASCENDING (memory order)
+  const int32_t* col_perm;     // [n_cols] site-order column of the c-th smallest offset
+  int64_t n_cols;
+};
+
+__global__ void __launch_bounds__(256)
+gather_cols_kernel(const float* __restrict__ in, int64_t rows, int64_t cols, const int32_t* __restrict__ perm,
+                   float* __restrict__ out) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    out[e] = in[(e / cols) * cols + perm[e % cols]];
+}
+
+inline int final_product(int64_t rows, int64_t n_tail, int64_t k, const float* left, const float* R, float* spare,
+                         float* d_out, const ChainScatter* sc, void*, int64_t, hipStream_t s) {
+  if (!sc) return ndmps_sgemm(0, 0, rows, n_tail, k, left, k, R, n_tail, d_out, n_tail, s);
+  // columns of R in memory order of the volume, then every element goes straight to its voxel
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(grid1d(k * n_tail)), dim3(256), 0, s, R, k, n_tail, sc->col_perm, spare);
+  NDMPS_LAUNCH_CHECK();
+  return ndmps_sgemm_indexed(rows, n_tail, k, left, k, nullptr, nullptr, 0, spare, n_tail, d_out, 0, sc->row_off,
+                             sc->col_off, s);
+}
+inline int final_product(int64_t rows, int64_t n_tail, int64_t k, const __bf16* left, const __bf16* R, __bf16*,
+                         __bf16* d_out, const ChainScatter*, void* tws, int64_t tws_bytes, hipStream_t s) {
+  return gemm_T(0, rows, n_tail, k, left, R, n_tail, d_out, tws, tws_bytes, s);
+}
+
 template <typename T>
 int chain_impl(int L, const int64_t* h_dims, const int64_t* h_bonds, const T* const* h_cores, T* d_dense, void* d_ws,
-               int64_t ws_bytes, ndmps_stream_t stream) {
+               int64_t ws_bytes, ndmps_stream_t stream, const ChainScatter* scatter = nullptr) {
   NDMPS_REQUIRE(L >= 1 && h_dims && h_bonds && h_cores && d_dense, "bad chain argument");
   NDMPS_REQUIRE(h_bonds[0] == 1 && h_bonds[L] == 1, "open boundary bonds must be 1");
   int64_t numel = 1;
@@ -848,8 +877,15 @@ int chain_impl(int L, const int64_t* h_dims, const int64_t* h_bonds, const T* co
     left = out;
     rows *= h_dims[i];
   }
-  if (j0 < L)
-    NDMPS_TRY(gemm_T(0, rows, n_tail, h_bonds[j0], left, R, n_tail, d_dense, tws, tws_bytes, s));
+  if (scatter)
+    NDMPS_REQUIRE(j0 < L && L >= 2 && scatter->n_cols == n_tail,
+                  "scatter tables are for %lld tail columns, the chain's tail has %lld", (long long)scatter->n_cols,
+                  (long long)(j0 < L ? n_tail : 0));
+  if (j0 < L) {
+    // R sits in one tail buffer (or is the last core itself); the other one is free for its reordered copy
+    T* spare = (R == ws_tail[0]) ? ws_tail[1] : ws_tail[0];
+    NDMPS_TRY(final_product(rows, n_tail, h_bonds[j0], left, R, spare, d_dense, scatter, tws, tws_bytes, s));
+  }
   NDMPS_REQUIRE(j0 < L || left == d_dense, "internal: chain result landed in the wrong buffer");
   return NDMPS_OK;
 }
@@ -859,6 +895,33 @@ extern "C" int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int6
                                         const float* const* h_cores, float* d_dense, void* d_ws,
                                         int64_t ws_bytes, ndmps_stream_t stream) {
   return chain_impl<float>(L, h_dims, h_bonds, h_cores, d_dense, d_ws, ws_bytes, stream);
+}
+
+// number of trailing columns the chain pre-contracts (product of the dims of the tail sites), 0 if none
+extern "C" int64_t ndmps_chain_tail_columns(int L, const int64_t* h_dims) {
+  if (L < 2 || !h_dims) return 0;
+  int64_t right = 1;
+  int taken = 0;
+  for (int i = L - 1; i >= 1; --i) {
+    if (right * h_dims[i] > kChainTailMax) break;
+    right *= h_dims[i];
+    ++taken;
+  }
+  return taken > 0 ? right : 0;
+}
+
+// Chain contraction that writes the C-order VOLUME: the inverse index permutation (core/ndmps.py:144-148) rides
+// on the last product, every element goes from the accumulator to its voxel (d_row_off / d_col_off /
+// d_col_perm: ndmps_plan_split_offsets for n_cols = ndmps_chain_tail_columns, columns sorted by offset).  The
+// site-order tensor is never written.
+extern "C" int ndmps_chain_contract_scatter_f32(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                                                const float* const* h_cores, float* d_out,
+                                                const int64_t* d_row_off, const int64_t* d_col_off,
+                                                const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
+                                                int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_row_off && d_col_off && d_col_perm && n_cols >= 1, "NULL scatter table");
+  ChainScatter sc{d_row_off, d_col_off, d_col_perm, n_cols};
+  return chain_impl<float>(L, h_dims, h_bonds, h_cores, d_out, d_ws, ws_bytes, stream, &sc);
 }
 
 extern "C" int ndmps_chain_contract_bf16(int L, const int64_t* h_dims, const int64_t* h_bonds,

