@@ -24,6 +24,7 @@ import contextlib
 import ctypes as C
 import gzip
 import io
+import os
 import threading
 
 import numpy as np
@@ -104,6 +105,7 @@ class _Plan:
         self.numel = int(np.prod(self.shape, dtype=np.int64))
 
         self._split = {}
+        self._split_vec4 = {}
 
     def split_tables(self, n_cols, device):
         """Device tables for the site-order tensor viewed as (numel / n_cols) x n_cols: element (r, c) sits at
@@ -120,11 +122,22 @@ class _Plan:
                 _lib.check(_lib.load().ndmps_plan_split_offsets(
                     self.handle, int(n_cols), row_off.ctypes.data_as(_lib.p_i64), col_off.ctypes.data_as(_lib.p_i64)))
                 perm = np.argsort(col_off, kind="stable")
+                col_sorted = np.ascontiguousarray(col_off[perm])
+                # 16-byte gathers are possible when the sorted offsets come in aligned runs of four
+                quads = col_sorted.reshape(-1, 4) if n_cols % 4 == 0 else None
+                self._split_vec4[key] = bool(
+                    quads is not None and np.all(quads[:, 0] % 4 == 0) and np.all(np.diff(quads, axis=1) == 1)
+                    and np.all(row_off % 4 == 0))
                 self._split[key] = (torch.from_numpy(row_off).to(device),
-                                    torch.from_numpy(np.ascontiguousarray(col_off[perm])).to(device),
+                                    torch.from_numpy(col_sorted).to(device),
                                     torch.from_numpy(perm.astype(np.int32)).to(device))
                 torch.cuda.synchronize(device)
             return self._split[key]
+
+    def gather_tables(self, n_cols, device):
+        """split_tables when the volume can be read through them 16 bytes at a time, else None."""
+        tables = self.split_tables(n_cols, device)
+        return tables if self._split_vec4[(int(n_cols), str(device))] else None
 
     def __del__(self):
         try:
@@ -268,6 +281,14 @@ class NDMPS:
             plan = _plan_for(shape, device.index)
             stream = _lib.stream_ptr()
             numel = plan.numel
+            dims = [int(q) for q in plan.qubit_size]
+            L = len(dims)
+            cdims = _lib.i64_array(dims)
+            mb = int(max_bond) if max_bond else 0
+            # fp32, bond-capped: the reshape stage rides on the first Gram pass and the first projection of the
+            # sweep (the volume is read through the permutation tables, no site-order tensor is formed)
+            n_merge = 0 if (bf16 or os.environ.get("NDMPS_NO_FUSED_ENCODE")) else int(lib.ndmps_tt_merge_columns(L, cdims, mb))
+            gather = plan.gather_tables(n_merge, device) if n_merge > 0 else None
             denses = []
             for x in xs:
                 if (norm or mode == "DCT") and bf16:
@@ -284,16 +305,15 @@ class NDMPS:
                                                       _dct_basis(n, device).data_ptr(), stream))
                     x = y
                 x = x.to(store)
+                if gather is not None:
+                    denses.append(x)  # read in place by the fused sweep, never written
+                    continue
                 dense = torch.empty(numel, dtype=store, device=device)
                 with _span("encode_permute"):
                     _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), esize, stream))
                 denses.append(dense)
             del xs, x
 
-            dims = [int(q) for q in plan.qubit_size]
-            L = len(dims)
-            cdims = _lib.i64_array(dims)
-            mb = int(max_bond) if max_bond else 0
             max_bonds = (C.c_int64 * (L + 1))()
             core_off = (C.c_int64 * (L + 1))()
             spec_off = (C.c_int64 * (L + 1))()
@@ -309,9 +329,16 @@ class NDMPS:
             dense_ptrs = (C.c_void_p * batch)(*[d.data_ptr() for d in denses])
             arena_ptrs = (C.c_void_p * batch)(*[a.data_ptr() for a in arenas])
             with _span("sweep"):
-                sweep = lib.ndmps_tt_sweep_batched_bf16 if bf16 else lib.ndmps_tt_sweep_batched_f32
-                _lib.check(sweep(batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds, spectra,
-                                 spec_off, ws.data_ptr(), ws.numel(), stream))
+                if gather is not None:
+                    row_off, col_off, col_perm = gather
+                    _lib.check(lib.ndmps_tt_sweep_batched_fused_f32(
+                        batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds, spectra, spec_off,
+                        row_off.data_ptr(), col_off.data_ptr(), col_perm.data_ptr(), n_merge, ws.data_ptr(), ws.numel(),
+                        stream))
+                else:
+                    sweep = lib.ndmps_tt_sweep_batched_bf16 if bf16 else lib.ndmps_tt_sweep_batched_f32
+                    _lib.check(sweep(batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds,
+                                     spectra, spec_off, ws.data_ptr(), ws.numel(), stream))
             del ws, denses
             objs = []
             for b in range(batch):
@@ -424,6 +451,8 @@ class NDMPS:
             stream = _lib.stream_ptr()
             dims = _lib.i64_array(self.mps.dims)
             n_tail = lib.ndmps_chain_tail_columns(len(self.mps.dims), dims) if self.mps.dtype == torch.float32 else 0
+            if os.environ.get("NDMPS_NO_FUSED_DECODE"):  # A/B timing
+                n_tail = 0
             if n_tail > 0:
                 # fp32: the inverse permutation rides on the last product of the chain; no site-order tensor
                 out = torch.empty(self._shape, dtype=torch.float32, device=device)

@@ -476,10 +476,14 @@ __device__ __forceinline__ float4 load4_as_f32(const __bf16* p) {
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
+// row_off / col_off (both or neither): element (r, c) of A at A[row_off[r] + col_off[c]] instead of A[r lda + c] --
+// the matrix is the C-order volume read through the index permutation (see GemmIndex); with vec_ok every aligned
+// group of four columns has consecutive offsets.
 template <int GW_TS, typename TIN>
 __global__ void __launch_bounds__(256)
 gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
-                 double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab, int vec_ok) {
+                 double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab, int vec_ok,
+                 const int64_t* __restrict__ row_off = nullptr, const int64_t* __restrict__ col_off = nullptr) {
   constexpr int GW_LD = GW_TS + 16;
   constexpr int NT = GW_TS / 32;       // MFMA tiles per wave and direction
   constexpr int SUB = GW_TS / 2;       // wave sub-tile edge
@@ -518,7 +522,11 @@ gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
       const int rr = e / QPR, c4 = (e % QPR) * 4;
       const int64_t row = r0 + rr;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-      if (row < r_end) {
+      if (row < r_end && row_off) {  // gathered: offsets additive in (row, column); vec_ok guaranteed by the host
+        const TIN* base = A + row_off[row];
+        if (i0 + c4 + 3 < n) x = load4_as_f32(base + col_off[i0 + c4]);
+        if (!diag && j0 + c4 + 3 < n) y = load4_as_f32(base + col_off[j0 + c4]);
+      } else if (row < r_end) {
         const TIN* base = A + row * lda;
         if (vec_ok && i0 + c4 + 3 < n) x = load4_as_f32(base + i0 + c4);
         else {
@@ -777,7 +785,7 @@ extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
 namespace {
 template <typename TIN>
 int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, void* d_ws, int64_t ws_bytes,
-             ndmps_stream_t stream) {
+             ndmps_stream_t stream, const int64_t* d_row_off = nullptr, const int64_t* d_col_off = nullptr) {
   NDMPS_REQUIRE(d_A && d_G, "NULL Gram operand");
   NDMPS_REQUIRE(m > 0 && n > 0 && lda >= n, "bad Gram extents m=%lld n=%lld lda=%lld", (long long)m,
                 (long long)n, (long long)lda);
@@ -790,6 +798,10 @@ int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, voi
   double* partial = (double*)d_ws;
   // four elements per load: 16 bytes of fp32, 8 bytes of bf16
   const int vec_ok = (lda % 4 == 0 && n % 4 == 0 && ((uintptr_t)d_A % (4 * sizeof(TIN))) == 0) ? 1 : 0;
+  if (d_row_off) {
+    NDMPS_REQUIRE(d_col_off && gram_use_wide(m, n) && n % 4 == 0 && ((uintptr_t)d_A % (4 * sizeof(TIN))) == 0,
+                  "gathered Gram needs the wide path (n >= 64, m >= 256), n %% 4 == 0 and an aligned base");
+  }
   if (gram_use_small(n)) {
     const int blocks = (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(m, 256 * 8), 1), kGramSmallBlocks);
     hipLaunchKernelGGL(gram_small_kernel<TIN>, dim3(blocks), dim3(256), 0, s, d_A, m, (int)n, lda, partial,
@@ -803,12 +815,12 @@ int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, voi
     NDMPS_REQUIRE(gw.n_slabs < 65536, "Gram slab count %d exceeds grid.y", gw.n_slabs);
     if (gram_wide_tile(n) == 128) {
       hipLaunchKernelGGL((gram_wide_kernel<128, TIN>), dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
-                         partial, gw.tiles_1d, gw.rows_per_slab, vec_ok);
+                         partial, gw.tiles_1d, gw.rows_per_slab, vec_ok, d_row_off, d_col_off);
       NDMPS_LAUNCH_CHECK();
       return launch_tile_reduce<128>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
     }
     hipLaunchKernelGGL((gram_wide_kernel<64, TIN>), dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
-                       partial, gw.tiles_1d, gw.rows_per_slab, vec_ok);
+                       partial, gw.tiles_1d, gw.rows_per_slab, vec_ok, d_row_off, d_col_off);
     NDMPS_LAUNCH_CHECK();
     return launch_tile_reduce<64>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
   }
@@ -833,6 +845,15 @@ int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, voi
 extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
                               void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
   return gram_any<float>(d_A, m, n, lda, d_G, d_ws, ws_bytes, stream);
+}
+
+// G = A^T A where element (r, c) of A is d_base[d_row_off[r] + d_col_off[c]] (the C-order volume read through the
+// index permutation; d_col_off in aligned runs of four consecutive offsets); wide path only (n >= 64, m >= 256)
+extern "C" int ndmps_gram_indexed_f32(const float* d_base, int64_t m, int64_t n, const int64_t* d_row_off,
+                                      const int64_t* d_col_off, double* d_G, void* d_ws, int64_t ws_bytes,
+                                      ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_row_off && d_col_off, "NULL offset table");
+  return gram_any<float>(d_base, m, n, n, d_G, d_ws, ws_bytes, stream, d_row_off, d_col_off);
 }
 
 // same with a bf16 matrix (products of two bf16 numbers are exact in fp32, let alone fp64)

@@ -194,6 +194,30 @@ __global__ void merge_basis_init_kernel(double* __restrict__ W, int64_t stride_w
   W[(int64_t)blockIdx.x * stride_w] = 1.0;  // W_L = [1]
 }
 
+// Fused reshape stage: the raw Gram pass reads the volume with its columns in MEMORY order (perm[c'] = site-order
+// column of the c'-th smallest offset): G'[a][b] = G[perm[a]][perm[b]].  Back to site order:
+__global__ void __launch_bounds__(256)
+unpermute_gram_kernel(const double* __restrict__ Gp, int64_t n, const int32_t* __restrict__ perm, double* __restrict__ G) {
+  const int64_t total = n * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    G[(int64_t)perm[e / n] * n + perm[e % n]] = Gp[e];
+}
+// ... and the projection multiplies by the basis with its rows in memory order: out[c'] = W[perm[c']]
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ W, int64_t rows, int64_t cols, const int32_t* __restrict__ perm,
+                   float* __restrict__ out) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    out[e] = W[(int64_t)perm[e / cols] * cols + e % cols];
+}
+
+struct SweepSource {           // the volume read through the index permutation (fp32, merged run only)
+  const int64_t* row_off;      // [numel / n_cols]
+  const int64_t* col_off;      // [n_cols], ascending, aligned runs of four consecutive offsets
+  const int32_t* col_perm;     // [n_cols]
+  int64_t n_cols;
+};
+
 constexpr int64_t kMergeMax = 512;  // largest raw Gram order of the merged sites
 
 // first site of the merged run, or L when nothing is merged (see the comment above)
@@ -368,10 +392,31 @@ inline int gemm_T(int transB, int64_t m, int64_t n, int64_t k, const __bf16* A, 
   return ndmps_gemm_bf16(transB, m, n, k, A, k, B, ldb, C, n, tws, tws_bytes, s);
 }
 
+// fp32 only: Gram and projection of the merged run through the permutation tables
+inline int gram_src(const float* vol, int64_t m, int64_t n, const SweepSource& src, double* G, void* ws, int64_t wsb,
+                    hipStream_t s) {
+  return ndmps_gram_indexed_f32(vol, m, n, src.row_off, src.col_off, G, ws, wsb, s);
+}
+inline int gram_src(const __bf16*, int64_t, int64_t, const SweepSource&, double*, void*, int64_t, hipStream_t) {
+  ndmps::set_error("the fused reshape stage is fp32 only");
+  return NDMPS_EINVAL;
+}
+inline int project_src(const float* vol, int64_t m, int64_t k, int64_t n, const SweepSource& src, const float* W,
+                       float* scratch, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d(n * k)), dim3(256), 0, s, W, n, k, src.col_perm, scratch);
+  NDMPS_LAUNCH_CHECK();
+  return ndmps_sgemm_indexed(m, k, n, vol, 0, src.row_off, src.col_off, 1, scratch, k, out, k, nullptr, nullptr, s);
+}
+inline int project_src(const __bf16*, int64_t, int64_t, int64_t, const SweepSource&, const __bf16*, __bf16*, __bf16*,
+                       hipStream_t) {
+  return NDMPS_EINVAL;
+}
+
 template <typename T>
 int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, double cutoff, int64_t max_bond,
                T* const* h_cores, const int64_t* h_core_offsets, int64_t* h_bonds_out, double* h_spectra,
-               const int64_t* h_spec_offsets, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+               const int64_t* h_spec_offsets, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream,
+               const SweepSource* src = nullptr) {
   NDMPS_REQUIRE(h_dense && h_dims && h_cores && h_core_offsets && h_bonds_out, "NULL sweep argument");
   NDMPS_REQUIRE(cutoff >= 0.0, "cutoff must be non-negative");
   SweepLayout lay;
@@ -407,6 +452,14 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
 
   std::vector<T*> cur(batch), nxt(batch);
   std::vector<int64_t> chi_r(batch, 1), cur_elems(batch, lay.numel), eig_n(batch), kept(batch);
+  if (src) {
+    // h_dense[b] is the C-order volume and stays untouched: the carried matrices ping-pong between the halves
+    // of the workspace buffer (the first one is already <= half the tensor)
+    NDMPS_REQUIRE(lay.merge_from < L && src->n_cols == lay.merge_n &&
+                      (lay.numel / lay.merge_n) * lay.merge_w <= lay.numel / 2,
+                  "the fused reshape stage needs a merged run of %lld columns (see ndmps_tt_merge_columns)",
+                  (long long)src->n_cols);
+  }
   for (int b = 0; b < batch; ++b) {
     cur[b] = h_dense[b];
     nxt[b] = other + (int64_t)b * lay.numel;
@@ -469,8 +522,17 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     const int i0 = lay.merge_from;
     const int64_t n0 = lay.merge_n, ldw = lay.merge_w, m0 = lay.numel / n0;
     const int64_t stride_top = n0 * n0, stride_w = n0 * ldw;
-    for (int b = 0; b < batch; ++b)
-      NDMPS_TRY(gram_T(cur[b], m0, n0, n0, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
+    for (int b = 0; b < batch; ++b) {
+      if (src) {
+        double* Gp = Tm + (int64_t)b * stride_top;  // columns in memory order; T is free until stage 1
+        NDMPS_TRY(gram_src(cur[b], m0, n0, *src, Gp, gram_ws, lay.gram_ws, s));
+        hipLaunchKernelGGL(unpermute_gram_kernel, dim3(grid1d(n0 * n0)), dim3(256), 0, s, Gp, n0, src->col_perm,
+                           Graw + (int64_t)b * stride_top);
+        NDMPS_LAUNCH_CHECK();
+      } else {
+        NDMPS_TRY(gram_T(cur[b], m0, n0, n0, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
+      }
+    }
     hipLaunchKernelGGL(merge_basis_init_kernel, dim3(batch), dim3(1), 0, s, Wm[0], stride_w);
     NDMPS_LAUNCH_CHECK();
     int wcur = 0;
@@ -525,8 +587,16 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     }
     for (int b = 0; b < batch; ++b) {  // carry = A_raw W (m0 x k)
       const int64_t k = chi_r[b];
-      NDMPS_TRY(gemm_T(0, m0, k, n0, cur[b], W32 + (int64_t)b * stride_w, k, nxt[b], tws, tws_bytes, s));
-      std::swap(cur[b], nxt[b]);
+      if (src) {
+        // T (fp64 scratch of the congruences, free now) holds the basis with its rows in memory order
+        T* wperm = reinterpret_cast<T*>(Tm + (int64_t)b * stride_top);
+        NDMPS_TRY(project_src(cur[b], m0, k, n0, *src, W32 + (int64_t)b * stride_w, wperm, nxt[b], s));
+        cur[b] = nxt[b];
+        nxt[b] = nxt[b] + lay.numel / 2;
+      } else {
+        NDMPS_TRY(gemm_T(0, m0, k, n0, cur[b], W32 + (int64_t)b * stride_w, k, nxt[b], tws, tws_bytes, s));
+        std::swap(cur[b], nxt[b]);
+      }
       cur_elems[b] = m0 * k;
     }
     i_start = i0 - 1;
@@ -599,6 +669,33 @@ extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int 
                                           int64_t ws_bytes, ndmps_stream_t stream) {
   return sweep_impl<float>(batch, h_dense, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets, h_bonds_out, h_spectra,
                            h_spec_offsets, d_ws, ws_bytes, stream);
+}
+
+// Order of the raw Gram matrix of the merged trailing run when the reshape stage can ride on it (0 otherwise):
+// the caller passes ndmps_plan_split_offsets tables for that many columns to the fused sweep.
+extern "C" int64_t ndmps_tt_merge_columns(int L, const int64_t* h_dims, int64_t max_bond) {
+  SweepLayout lay;
+  if (!h_dims || sweep_layout(L, h_dims, max_bond, 1, lay) != NDMPS_OK) return 0;
+  if (lay.merge_from >= L || (lay.numel / lay.merge_n) * lay.merge_w > lay.numel / 2) return 0;
+  if (lay.merge_n < 64 || lay.numel / lay.merge_n < 256 || lay.merge_n % 4 != 0) return 0;  // wide Gram path only
+  return lay.merge_n;
+}
+
+// The fp32 sweep reading the C-order VOLUMES through the index permutation (core/ndmps.py:66-71 fused into the
+// first Gram pass and the first projection): h_volume[b] are left untouched, no site-order tensor is formed.
+// Tables: ndmps_plan_split_offsets for n_cols = ndmps_tt_merge_columns(...), columns sorted by offset
+// (d_col_off ascending, in aligned runs of four consecutive offsets; d_col_perm[c] = site-order column).
+extern "C" int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h_volume, int L, const int64_t* h_dims,
+                                                double cutoff, int64_t max_bond, float* const* h_cores,
+                                                const int64_t* h_core_offsets, int64_t* h_bonds_out,
+                                                double* h_spectra, const int64_t* h_spec_offsets,
+                                                const int64_t* d_row_off, const int64_t* d_col_off,
+                                                const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
+                                                int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_row_off && d_col_off && d_col_perm && n_cols >= 1, "NULL permutation table");
+  SweepSource src{d_row_off, d_col_off, d_col_perm, n_cols};
+  return sweep_impl<float>(batch, (float* const*)h_volume, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets,
+                           h_bonds_out, h_spectra, h_spec_offsets, d_ws, ws_bytes, stream, &src);
 }
 
 // bf16 storage: the site-order tensors, the carried matrices and the cores are bf16 in HBM; Gram matrices,

@@ -230,6 +230,25 @@ int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const in
                                double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
                                int64_t ws_bytes, ndmps_stream_t stream);
 
+/* The fp32 sweep with the reshape stage fused in (core/ndmps.py:66-71 + :74): the raw Gram pass and the
+ * projection of the merged trailing run read the C-order volumes through the index permutation; h_volume[b] is
+ * left untouched and no site-order tensor is formed.  n_cols = ndmps_tt_merge_columns(L, dims, max_bond)
+ * (0: not available for this shape / bond cap); tables from ndmps_plan_split_offsets(plan, n_cols, ...) with the
+ * columns sorted by offset (d_col_off ascending and in aligned runs of four consecutive offsets, d_col_perm[c] =
+ * site-order column of the c-th smallest offset). */
+int64_t ndmps_tt_merge_columns(int L, const int64_t* h_dims, int64_t max_bond);
+int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h_volume, int L, const int64_t* h_dims,
+                                     double cutoff, int64_t max_bond, float* const* h_cores,
+                                     const int64_t* h_core_offsets, int64_t* h_bonds_out,
+                                     double* h_spectra, const int64_t* h_spec_offsets,
+                                     const int64_t* d_row_off, const int64_t* d_col_off,
+                                     const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
+                                     int64_t ws_bytes, ndmps_stream_t stream);
+/* G = A^T A where element (r, c) of A is d_base[d_row_off[r] + d_col_off[c]] (wide path: n >= 64, m >= 256) */
+int ndmps_gram_indexed_f32(const float* d_base, int64_t m, int64_t n, const int64_t* d_row_off,
+                           const int64_t* d_col_off, double* d_G, void* d_ws, int64_t ws_bytes,
+                           ndmps_stream_t stream);
+
 /* The same sweep on bf16 storage: site-order tensors, carried matrices and cores are bf16 in HBM, Gram
  * matrices / eigen-decompositions / bases fp64, products fp32-accumulated on the bf16 MFMA.  Layout and
  * workspace queries are those of the fp32 sweep (offsets count elements; its workspace size is an upper bound). */

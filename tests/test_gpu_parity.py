@@ -792,6 +792,62 @@ def test_fused_decode_is_bit_identical_to_chain_plus_permute(shape, chi):
     assert (n_tail > 0) == (len(obj.mps.dims) >= 2 and obj.mps.dims[-1] <= 4096)
 
 
+@pytest.mark.parametrize("shape,chi,mode", [((64, 64, 64), 16, "Std"), ((128, 128, 128), 64, "Std"),
+                                            ((128, 128, 128), 32, "DCT"), ((64, 64, 64), 32, "DCT")], ids=str)
+def test_fused_encode_matches_permute_then_sweep(shape, chi, mode):
+    """The bond-capped fp32 sweep reads the volume through the permutation tables (raw Gram pass + projection of
+    the merged run); no site-order tensor is formed and the input is left untouched.  The Gram matrices -- hence
+    the cores of the merged sites -- are bit-identical to the unfused route (same sums in the same row order);
+    the carried matrix sums its products over the columns in memory order instead of site order, so everything
+    downstream agrees to fp32 rounding."""
+    lib = _lib.load()
+    x = torch.from_numpy(synthetic_mri(shape, seed=13)).to(DEV)
+    keep = x.clone()
+    plan = _plan_for(shape, 0)
+    dims = [int(q) for q in plan.qubit_size]
+    L = len(dims)
+    n_merge = lib.ndmps_tt_merge_columns(L, _lib.i64_array(dims), chi)
+    assert n_merge > 0 and plan.gather_tables(n_merge, torch.device(DEV)) is not None
+    fused = NDMPS.from_tensor(x, max_bond=chi, mode=mode)
+    assert torch.equal(x, keep)
+    # the unfused route through the C ABI: permute, then the plain sweep
+    xin = x
+    if mode == "DCT":
+        from imgcompressionmps_amd.core.ndmps import _dct_basis
+        xin = torch.empty_like(x)
+        _lib.check(lib.ndmps_dct_last_f32(x.data_ptr(), xin.data_ptr(), x.numel() // shape[-1], shape[-1],
+                                          _dct_basis(shape[-1], torch.device(DEV)).data_ptr(), sp()))
+    dense = torch.empty(x.numel(), dtype=torch.float32, device=DEV)
+    _lib.check(lib.ndmps_encode_permute(plan.handle, xin.data_ptr(), dense.data_ptr(), 4, sp()))
+    cdims = _lib.i64_array(dims)
+    core_off = (C.c_int64 * (L + 1))()
+    spec_off = (C.c_int64 * (L + 1))()
+    max_bonds = (C.c_int64 * (L + 1))()
+    _lib.check(lib.ndmps_tt_layout(L, cdims, chi, max_bonds, core_off, spec_off, None))
+    nbytes = lib.ndmps_tt_sweep_batched_workspace_bytes(1, L, cdims, chi)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    arena = torch.zeros(int(core_off[L]), dtype=torch.float32, device=DEV)
+    bonds = (C.c_int64 * (L + 1))()
+    _lib.check(lib.ndmps_tt_sweep_batched_f32(1, (C.c_void_p * 1)(dense.data_ptr()), L, cdims, 1e-10, chi,
+                                              (C.c_void_p * 1)(arena.data_ptr()), core_off, bonds, None, spec_off,
+                                              ws.data_ptr(), nbytes, sp()))
+    assert [int(b) for b in bonds][1:-1] == fused.bond_sizes()
+    merged_from = next(i for i in range(1, L) if int(np.prod(dims[i:])) == n_merge)
+    from imgcompressionmps_amd.core.mps import DeviceMPS
+
+    ref_cores = []
+    for i, core in enumerate(fused.mps.cores):
+        k0, k1 = int(bonds[i]), int(bonds[i + 1])
+        ref = arena[int(core_off[i]): int(core_off[i]) + k0 * dims[i] * k1].view(k0, dims[i], k1)
+        ref_cores.append(ref)
+        if i >= merged_from:
+            assert torch.equal(core, ref), i  # Gram-derived: bit-identical
+    # cores further left are eigenvectors of Gram matrices of the carried matrix (differently rounded, and
+    # inside noise-floor clusters individually ill-conditioned): compare what they represent
+    a, b = fused.mps.to_dense(), DeviceMPS(ref_cores).to_dense()
+    assert float((a - b).norm() / b.norm()) <= 2e-6
+
+
 def test_minmax_many_matches_single():
     ts = [torch.randn(n, device=DEV) for n in (1, 17, 4096, 100003)]
     got = hft.minmax_many(ts)
