@@ -7,7 +7,8 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies a wide 
 (16 bytes per lane) at exactly half its bytes; kernels listed in DOUBLE_FETCH read that way and get x2.
 WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
 
-usage: python tools/pmc_to_json.py FETCH_DIR WRITE_DIR "command that was profiled" [out.json]"""
+usage: python tools/pmc_to_json.py FETCH_DIR WRITE_DIR "command that was profiled" [out.json [kernel,kernel,...]]
+(with a kernel list, only those entries are written and the other entries of an existing out.json are kept)"""
 import collections
 import csv
 import glob
@@ -51,6 +52,14 @@ def main():
             "command": sys.argv[3],
         }
     path = sys.argv[4] if len(sys.argv) > 4 else "profiles/r02_pmc_summary.json"
+    only = sys.argv[5].split(",") if len(sys.argv) > 5 else None  # keep other kernels' entries of an existing file
+    if only is not None:
+        out = {k: v for k, v in out.items() if k in only}
+        if os.path.exists(path):
+            with open(path) as fh:
+                merged = json.load(fh)
+            merged.update(out)
+            out = merged
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
