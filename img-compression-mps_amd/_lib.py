@@ -82,6 +82,8 @@ SIGNATURES = {
     "ndmps_syevd_topk_stamps_offset": (i64, [i64, C.c_int, i64]),
     "ndmps_syevd_topk_values_f64": (C.c_int, [C.c_int, vp, i64, p_i64, vp, i64, vp, i64, i64, vp, i64, vp]),
     "ndmps_syevd_topk_vectors_f64": (C.c_int, [C.c_int, p_i64, p_i64, i64, vp, i64, p_int, vp]),
+    "ndmps_syevd_topk_vectors_auto_f64": (C.c_int, [C.c_int, p_i64, i64, C.c_double, vp, vp, i64, vp, vp, i64, vp]),
+    "ndmps_tt_sweep_pads_cores": (C.c_int, [C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_workspace_bytes": (i64, [C.c_int, C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
                                              C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, i64, vp]),

@@ -340,16 +340,24 @@ class NDMPS:
                     _lib.check(sweep(batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds,
                                      spectra, spec_off, ws.data_ptr(), ws.numel(), stream))
             del ws, denses
+            # ranks decided on the device: cores sit in the arena in padded shape (cap_i, d_i, cap_{i+1}), zeros
+            # beyond the actual bonds; slicing is a no-op whenever the caps bind (the usual case)
+            padded = bool(lib.ndmps_tt_sweep_pads_cores(L, cdims, mb))
             objs = []
             for b in range(batch):
                 cores, spec_list = [], [None] * L
                 left = 1
                 for i in range(L):
                     k0, k1 = int(bonds[b * (L + 1) + i]), int(bonds[b * (L + 1) + i + 1])
-                    n_el = k0 * dims[i] * k1
-                    view = arenas[b][int(core_off[i]): int(core_off[i]) + n_el].view(k0, dims[i], k1)
-                    # truncated arenas are compact, keep the views; exact sweeps own worst-case arenas
-                    cores.append(view if mb else view.clone())
+                    if padded:
+                        c0, c1 = int(max_bonds[i]), int(max_bonds[i + 1])
+                        full = arenas[b][int(core_off[i]): int(core_off[i]) + c0 * dims[i] * c1].view(c0, dims[i], c1)
+                        cores.append(full[:k0, :, :k1].contiguous())
+                    else:
+                        n_el = k0 * dims[i] * k1
+                        view = arenas[b][int(core_off[i]): int(core_off[i]) + n_el].view(k0, dims[i], k1)
+                        # truncated arenas are compact, keep the views; exact sweeps own worst-case arenas
+                        cores.append(view if mb else view.clone())
                     if i >= 1:
                         cnt = min(left, dims[i] * k1)
                         base = b * spec_total + int(spec_off[i])

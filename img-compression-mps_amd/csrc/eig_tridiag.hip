@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
 // flight while block t is applied (a reflector takes ~0.1 us to apply, a global access several times that).
 // grid (ceil(k / (256 / SEG)), B), 256 threads; LDS 2 * RB * SEG * R doubles.
 template <int SEG, int R, int RB>
-__global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict__ desc, TrdWork w) {
+__global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int k_fill) {
   constexpr int NP = SEG * R;             // padded order
   constexpr int PER = RB * NP / 256;      // doubles per thread and block
   static_assert(RB * NP % 256 == 0, "block must divide over the workgroup");
@@ -839,7 +839,13 @@ __global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict
   const int tid = threadIdx.x;
   const int seg = tid % SEG;
   const int c = blockIdx.x * (256 / SEG) + tid / SEG;
-  if (blockIdx.x * (256 / SEG) >= k) return;
+  if ((int)blockIdx.x * (256 / SEG) >= k) {
+    // columns beyond the rank, up to k_fill, are defined as zero (rank decided on the device: the caller's
+    // buffers are sized for the bond cap and the kept columns are a prefix)
+    if (c < min(k_fill, n))
+      for (int i = seg; i < n; i += SEG) d.V_out[(int64_t)i * n + c] = 0.0;
+    return;
+  }
   const bool live = c < k;
   const int64_t b = blockIdx.y;
   const double* Z = w.Z + b * w.n_max * kp;
@@ -930,6 +936,44 @@ __global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict
       const int i = seg + SEG * r;
       if (i < n) d.V_out[(int64_t)i * n + c] = sg * x[r];
     }
+  } else if (c < min(k_fill, n)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = seg + SEG * r;
+      if (i < n) d.V_out[(int64_t)i * n + c] = 0.0;
+    }
+  }
+}
+
+__global__ void trd_status_kernel(const TrdDesc* __restrict__ desc, int batch, int* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < batch) out[b] = desc[b].status;
+}
+
+// Rank decision on the device (the rule of kept_rank in tt.hip: singular values s_i = sqrt(max(w_i, 0)); keep
+// s_i > cutoff * s_0, at least one, at most k_cap): sets desc.k and reports rank and spectrum.
+__global__ void __launch_bounds__(128)
+trd_rank_kernel(TrdDesc* __restrict__ desc, int k_cap, double cutoff, int* __restrict__ ranks, double* __restrict__ spectra,
+                int64_t spectra_stride) {
+  TrdDesc& d = desc[blockIdx.x];
+  const int kk = min(k_cap, d.n);
+  const double s0 = sqrt(fmax(d.w_out[0], 0.0));
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < kk; i += 128) {
+    const double si = sqrt(fmax(d.w_out[i], 0.0));
+    if (spectra) spectra[(int64_t)blockIdx.x * spectra_stride + i] = si;
+    mine += si > cutoff * s0;
+  }
+  if (mine) atomicAdd(&cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int k = min(max(cnt, 1), kk);
+    d.k = k;
+    d.status = 0;
+    ranks[blockIdx.x] = k;
   }
 }
 
@@ -1130,6 +1174,64 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
   return NDMPS_OK;
 }
 
+namespace {
+// inverse iteration + back-transformation for ranks already stored in the descriptors; kk: largest rank any
+// matrix may have (sizes the launches), k_fill: columns zero-filled beyond a matrix's rank
+int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* desc, const TrdWork& w, hipStream_t s) {
+  const unsigned B = (unsigned)batch;
+  const int k16 = (kk + 15) & ~15;
+  hipLaunchKernelGGL(trd_invit_kernel, dim3(1, B), dim3(512), std::max((size_t)k16 * (k16 + 1) * 8, (size_t)n_max * 16), s, desc,
+                     w);
+  const int cols = std::max(kk, k_fill);
+  // rows per lane of the back-transform: n <= SEG * R; RB reflectors of SEG * R doubles per LDS block
+  const int per32 = (int)ndmps::ceil_div(n_max, 32), per64 = (int)ndmps::ceil_div(n_max, 64);
+#define NDMPS_BACK(SEG, R, RB)                                                                            \
+  hipLaunchKernelGGL((trd_back_kernel<SEG, R, RB>), dim3(ndmps::ceil_div(cols, 256 / SEG), B), dim3(256), \
+                     (size_t)2 * RB * SEG * R * sizeof(double), s, desc, w, k_fill)
+  if (per32 <= 4) NDMPS_BACK(32, 4, 8);
+  else if (per32 <= 8) NDMPS_BACK(32, 8, 8);
+  else if (per32 <= 16) NDMPS_BACK(32, 16, 8);
+  else if (per32 <= 32) NDMPS_BACK(32, 32, 4);
+  else if (per64 <= 32) NDMPS_BACK(64, 32, 2);
+  else NDMPS_BACK(64, 64, 1);
+#undef NDMPS_BACK
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+}  // namespace
+
+// Phase 2 with the rank decided ON THE DEVICE from the eigenvalues of phase 1: k_b = number of singular values
+// sqrt(w_i) above cutoff * sqrt(w_0), at least 1, at most k_cap.  Columns k_b .. k_cap-1 of V are zero-filled, so
+// callers size everything by k_cap and never wait for the rank.  d_ranks[b] (device) receives k_b, d_spectra (may
+// be NULL) the k_cap leading singular values at stride spectra_stride, d_status[b] (may be NULL) != 0 if the
+// orthonormalisation of matrix b broke down.  Fully asynchronous on `stream`.
+extern "C" int ndmps_syevd_topk_vectors_auto_f64(int batch, const int64_t* h_n, int64_t k_cap, double cutoff,
+                                                 int* d_ranks, double* d_spectra, int64_t spectra_stride,
+                                                 int* d_status, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  int64_t n_max = 0;
+  NDMPS_TRY(trd_check_sizes(batch, h_n, n_max));
+  NDMPS_REQUIRE(d_ranks, "NULL rank output");
+  NDMPS_REQUIRE(k_cap >= 1 && k_cap <= kMaxK && cutoff >= 0.0, "k_cap=%lld outside [1, %d] or negative cutoff",
+                (long long)k_cap, kMaxK);
+  const TrdLayout l = trd_layout(n_max, batch, std::min(k_cap, n_max));
+  if (d_ws == nullptr || ws_bytes < l.total) {
+    ndmps::set_error("syevd_topk workspace too small: %lld < %lld", (long long)ws_bytes, (long long)l.total);
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  TrdWork w = trd_work(l, d_ws);
+  TrdDesc* desc = (TrdDesc*)((char*)d_ws + l.off_desc);
+  const int kk = (int)std::min(k_cap, n_max);
+  hipLaunchKernelGGL(trd_rank_kernel, dim3(batch), dim3(128), 0, s, desc, kk, cutoff, d_ranks, d_spectra, spectra_stride);
+  NDMPS_LAUNCH_CHECK();
+  NDMPS_TRY(trd_launch_vectors(batch, n_max, kk, kk, desc, w, s));
+  if (d_status) {
+    hipLaunchKernelGGL(trd_status_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch, d_status);
+    NDMPS_LAUNCH_CHECK();
+  }
+  return NDMPS_OK;
+}
+
 // Phase 2: the first h_k[b] eigenvectors of matrix b into columns 0..k-1 of its V (ld n).  Same workspace,
 // untouched since phase 1.  Asynchronous on `stream`; *h_status (may be NULL) is filled only when the call
 // synchronises, i.e. when h_status is given.
@@ -1153,29 +1255,13 @@ extern "C" int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const
                   (long long)h_k[b]);
     kk = std::max(kk, (int)h_k[b]);
   }
-  const unsigned B = (unsigned)batch;
   for (int base = 0; base < batch; base += 256) {
     RankChunk chunk;
     const int count = std::min(256, batch - base);
     for (int t = 0; t < count; ++t) chunk.v[t] = (int)h_k[base + t];
     hipLaunchKernelGGL(trd_setk_kernel, dim3(1), dim3(256), 0, s, desc, chunk, base, count);
   }
-  const int k16 = (kk + 15) & ~15;
-  hipLaunchKernelGGL(trd_invit_kernel, dim3(1, B), dim3(512), std::max((size_t)k16 * (k16 + 1) * 8, (size_t)n_max * 16), s, desc,
-                     w);
-  // rows per lane of the back-transform: n <= SEG * R; RB reflectors of SEG * R doubles per LDS block
-  const int per32 = (int)ndmps::ceil_div(n_max, 32), per64 = (int)ndmps::ceil_div(n_max, 64);
-#define NDMPS_BACK(SEG, R, RB)                                                                          \
-  hipLaunchKernelGGL((trd_back_kernel<SEG, R, RB>), dim3(ndmps::ceil_div(kk, 256 / SEG), B), dim3(256), \
-                     (size_t)2 * RB * SEG * R * sizeof(double), s, desc, w)
-  if (per32 <= 4) NDMPS_BACK(32, 4, 8);
-  else if (per32 <= 8) NDMPS_BACK(32, 8, 8);
-  else if (per32 <= 16) NDMPS_BACK(32, 16, 8);
-  else if (per32 <= 32) NDMPS_BACK(32, 32, 4);
-  else if (per64 <= 32) NDMPS_BACK(64, 32, 2);
-  else NDMPS_BACK(64, 64, 1);
-#undef NDMPS_BACK
-  NDMPS_LAUNCH_CHECK();
+  NDMPS_TRY(trd_launch_vectors(batch, n_max, kk, 0, desc, w, s));
   if (h_status) {
     std::vector<TrdDesc> host(batch);
     NDMPS_CHECK_HIP(hipMemcpyAsync(host.data(), desc, sizeof(TrdDesc) * batch, hipMemcpyDeviceToHost, s));

@@ -285,6 +285,8 @@ struct SweepLayout {
   int64_t merge_n = 0;        // order of its raw Gram matrix
   int64_t merge_w = 0;        // leading dimension of the accumulated bases
   int64_t transpose_bytes = 0;  // bf16 path: transposed copy of the merged basis
+  bool device_rank = false;   // every site on the direct solver: ranks decided on the device, padded cores
+  int64_t spec_stride = 0;    // singular values kept per site and volume on the device
   int64_t workspace = 0;      // for the batch size it was computed for
 };
 
@@ -325,6 +327,14 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
     out.small_max = std::max(out.small_max, out.merge_n);
     out.gram_ws = std::max(out.gram_ws, gram_ws_bound(out.merge_n));
   }
+  // Rank decision on the device: possible when every site's eigenproblem (order min(rows, d_i cap_{i+1}) with
+  // the bonds at their caps) goes to the direct top-k solver.  The sweep then sizes everything by the caps,
+  // zero-fills the columns beyond a volume's rank and never waits for the host between sites.
+  out.device_rank = max_bond > 0 && max_bond <= ndmps_syevd_topk_max_k() && !getenv("NDMPS_SWEEP_HOST_RANK") &&
+                    !getenv("NDMPS_SWEEP_JACOBI");
+  for (int i = 1; i < L && out.device_rank; ++i)
+    if (std::min(left[i], dims[i] * out.max_bonds[i + 1]) > ndmps_syevd_topk_max_n()) out.device_rank = false;
+  out.spec_stride = max_bond > 0 ? std::min<int64_t>(max_bond, out.small_max) : 0;
   const int64_t sq = out.small_max * out.small_max;
   int64_t used = 0;
   used = arena_bytes(used, 4, (int64_t)batch * out.numel);              // second carry buffer per volume
@@ -343,6 +353,8 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
   used = arena_bytes(used, 4, (int64_t)batch * out.merge_n * out.merge_w);      // fp32 / bf16 copy for the projection
   out.transpose_bytes = ndmps_gemm_bf16_workspace_bytes(0, std::max<int64_t>(out.merge_w, 1), std::max<int64_t>(out.merge_n, 1));
   used = arena_bytes(used, 1, out.transpose_bytes);
+  used = arena_bytes(used, 4, (int64_t)2 * L * batch);                          // device ranks, status per site
+  used = arena_bytes(used, 8, (int64_t)L * batch * out.spec_stride);            // device spectra per site
   out.workspace = ndmps::round_up(used, 256) + 256;
   return NDMPS_OK;
 }
@@ -448,6 +460,11 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
   T* W32 = ar.take<T>((int64_t)batch * lay.merge_n * lay.merge_w);
   const int64_t tws_bytes = lay.transpose_bytes;
   char* tws = ar.take<char>(tws_bytes);
+  int* d_ranks = ar.take<int>((int64_t)2 * L * batch);
+  int* d_status = d_ranks ? d_ranks + (int64_t)L * batch : nullptr;
+  double* d_spec = ar.take<double>((int64_t)L * batch * lay.spec_stride);
+  const bool dev_rank = lay.device_rank;
+  NDMPS_REQUIRE(d_ranks && (d_spec || lay.spec_stride == 0), "workspace carve failed");
   NDMPS_REQUIRE(Graw && Tm && Wm[0] && Wm[1] && W32 && tws, "workspace carve failed");
 
   std::vector<T*> cur(batch), nxt(batch);
@@ -478,6 +495,16 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     for (int b = 0; b < batch; ++b) site_n = std::max(site_n, eig_n[b]);
     const bool topk = use_topk(site_n, max_bond);
     const int64_t k_cap = std::min<int64_t>(max_bond, site_n);
+    if (dev_rank) {
+      // no host round trip: eigenvalues -> rank (device) -> k_b eigenvectors, the other columns up to the cap zero
+      NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
+                                            ev_ws_bytes, s));
+      NDMPS_TRY(ndmps_syevd_topk_vectors_auto_f64(batch, eig_n.data(), k_cap, std::max(cutoff, kCutoffFloor),
+                                                  d_ranks + (int64_t)i * batch, d_spec + (int64_t)i * batch * lay.spec_stride,
+                                                  lay.spec_stride, d_status + (int64_t)i * batch, ev_ws, ev_ws_bytes, s));
+      for (int b = 0; b < batch; ++b) kept[b] = k_cap;
+      return NDMPS_OK;
+    }
     if (topk)
       NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
                                             ev_ws_bytes, s));
@@ -657,10 +684,43 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
   for (int b = 0; b < batch; ++b)
     NDMPS_CHECK_HIP(hipMemcpyAsync(h_cores[b] + h_core_offsets[0], cur[b], cur_elems[b] * sizeof(T),
                                    hipMemcpyDeviceToDevice, s));
+  if (dev_rank && L > 1) {
+    std::vector<int> host_i((size_t)2 * L * batch);
+    std::vector<double> host_s((size_t)L * batch * lay.spec_stride);
+    NDMPS_CHECK_HIP(hipMemcpyAsync(host_i.data(), d_ranks, host_i.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!host_s.empty())
+      NDMPS_CHECK_HIP(hipMemcpyAsync(host_s.data(), d_spec, host_s.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+    for (int i = 1; i < L; ++i)
+      for (int b = 0; b < batch; ++b) {
+        if (host_i[(size_t)L * batch + (size_t)i * batch + b] != 0) {
+          ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", i, b);
+          return NDMPS_ENOCONV;
+        }
+        h_bonds_out[(int64_t)b * (L + 1) + i] = host_i[(size_t)i * batch + b];
+        if (h_spectra && h_spec_offsets) {
+          const int64_t room = h_spec_offsets[i + 1] - h_spec_offsets[i];
+          double* dst = h_spectra + (int64_t)b * spec_total + h_spec_offsets[i];
+          const int64_t have = std::min(room, lay.spec_stride);
+          for (int64_t t = 0; t < room; ++t)
+            dst[t] = t < have ? host_s[((size_t)i * batch + b) * lay.spec_stride + t] : 0.0;
+        }
+      }
+    return NDMPS_OK;
+  }
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   return NDMPS_OK;
 }
 }  // namespace
+
+// 1 when the sweep for these site dims and this bond cap decides ranks on the device: cores are then written at
+// the layout's offsets in PADDED shape (max_bonds[i], d_i, max_bonds[i+1]) with zeros beyond the actual bonds
+// (h_bonds_out), and the caller slices them; 0: cores are compact (bonds[i], d_i, bonds[i+1]).
+extern "C" int ndmps_tt_sweep_pads_cores(int L, const int64_t* h_dims, int64_t max_bond) {
+  SweepLayout lay;
+  if (!h_dims || sweep_layout(L, h_dims, max_bond, 1, lay) != NDMPS_OK) return 0;
+  return lay.device_rank ? 1 : 0;
+}
 
 extern "C" int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const int64_t* h_dims,
                                           double cutoff, int64_t max_bond, float* const* h_cores,

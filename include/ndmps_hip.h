@@ -195,6 +195,13 @@ int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t stride_G, 
                                 int64_t k_max, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
 int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const int64_t* h_k, int64_t k_max,
                                  void* d_ws, int64_t ws_bytes, int* h_status, ndmps_stream_t stream);
+/* Phase 2 with the rank decided ON THE DEVICE from phase 1's eigenvalues: k_b = #{i < k_cap : sqrt(w_i) > cutoff
+ * sqrt(w_0)}, at least 1.  Columns k_b .. k_cap-1 of V are zero-filled, so a caller sizes everything by k_cap and
+ * never waits for the rank.  d_ranks[b] (device) receives k_b, d_spectra (may be NULL) the k_cap leading singular
+ * values at stride spectra_stride, d_status (may be NULL) the breakdown flags.  Fully asynchronous. */
+int ndmps_syevd_topk_vectors_auto_f64(int batch, const int64_t* h_n, int64_t k_cap, double cutoff,
+                                      int* d_ranks, double* d_spectra, int64_t spectra_stride,
+                                      int* d_status, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * MPS sweep: replaces quimb MatrixProductState.from_dense (core/ndmps.py:74).
@@ -222,6 +229,11 @@ int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cuto
  * evaluation/benchmark.py:73-76): h_dense[b] / h_cores[b] are per-volume device pointers,
  * h_bonds_out is batch x (L+1), h_spectra batch x h_spec_offsets[L].  The volumes advance
  * through the sites in lockstep so each site's eigenproblems are one batched solve. */
+/* 1 when the sweep for these site dims and bond cap decides the ranks on the device (every site on the direct
+ * top-k solver; no host round trip between sites): cores are then written at the layout's offsets in PADDED shape
+ * (max_bonds[i], d_i, max_bonds[i+1]) with zeros beyond the actual bonds reported in h_bonds_out, and the caller
+ * slices them.  0: cores are compact (bonds[i], d_i, bonds[i+1]). */
+int ndmps_tt_sweep_pads_cores(int L, const int64_t* h_dims, int64_t max_bond);
 int64_t ndmps_tt_sweep_batched_workspace_bytes(int batch, int L, const int64_t* h_dims,
                                                int64_t max_bond);
 int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const int64_t* h_dims,
