@@ -43,7 +43,7 @@ def parse(argv=None):
     ap.add_argument("--chi", type=int, default=64)
     ap.add_argument("--mode", default="Std", choices=["Std", "DCT"])
     ap.add_argument("--batch", type=int, default=64, help="independent volumes per GPU per step")
-    ap.add_argument("--groups", type=int, default=4,
+    ap.add_argument("--groups", type=int, default=2,
                     help="concurrent groups (host thread + HIP stream each) the batch is cut into; "
                          "volumes of a group are encoded in lockstep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
