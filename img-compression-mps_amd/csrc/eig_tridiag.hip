@@ -61,6 +61,8 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   double* Z;           // [B][n_max][kp] eigenvectors of T
   double* lu;          // [B][4][n_max][kp] dl, 1/d, du, du2 of the pivoted factorisations
   unsigned char* piv;  // [B][n_max][kp]
+  double* Tw;          // [B][t_stride] WY factors of the reflector groups (back-transformation)
+  int64_t t_stride;
   long long* stamps;   // [B][16] wall-clock (100 MHz) marks of the single-workgroup kernels' phases (tools/trd_probe.py)
   int n_max, lda, kp;
 };
@@ -827,13 +829,66 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
 // V = H_0 H_1 ... H_{n-2} Z on k columns.  A column lives in the registers of SEG lanes (row i in lane
 // i mod SEG, slot i / SEG), so v^T z is a shuffle reduction and a reflector costs no barrier.  Reflectors
 // come through LDS in blocks of RB rows of Vh, double-buffered: the global loads of block t + 1 are in
-// flight while block t is applied (a reflector takes ~0.1 us to apply, a global access several times that).
+// flight while block t is applied.  Inside a block, WYB consecutive reflectors are applied together in compact WY
+// form, H_{j} ... H_{j+WYB-1} = I - V T V^T (T from trd_wy_kernel): their WYB dot products and shuffle
+// reductions are independent, so the dependent chain per reflector shrinks by ~WYB (one reflector at a time:
+// 0.49 us each, the chain dot -> reduce -> update).
 // grid (ceil(k / (256 / SEG)), B), 256 threads; LDS 2 * RB * SEG * R doubles.
-template <int SEG, int R, int RB>
-__global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int k_fill) {
+//
+// Reflectors are numbered from the top, u = (n - 2) - j (u = 0 is applied first); WY group g holds u in
+// [g WYB, (g + 1) WYB).  Inside a group a = WYB - 1 - (u mod WYB) ascends with j.
+// trd_wy_kernel: T (upper triangular, LAPACK dlarft forward / columnwise) of every group:
+//   T[a][a] = tau_a,  T[0:a, a] = -tau_a T[0:a, 0:a] (V[:, 0:a]^T v_a).     grid (groups, B), 64 threads.
+template <int WYB>
+__global__ void __launch_bounds__(64) trd_wy_kernel(const TrdDesc* __restrict__ desc, TrdWork w, double* __restrict__ Tw,
+                                                   int64_t t_stride) {
+  const TrdDesc& d = desc[blockIdx.y];
+  const int n = d.n, lda = w.lda;
+  const int jtop = n - 2;
+  const int g = blockIdx.x;
+  if (g * WYB > jtop) return;
+  const int64_t b = blockIdx.y;
+  const double* Vh = w.Vh + b * w.n_max * lda;
+  const double* tt = w.tau + b * w.n_max;
+  const int lane = threadIdx.x;
+  __shared__ double G[WYB][WYB];
+  __shared__ double T[WYB][WYB];
+  // j of ascending index a: j_a = jtop - (g WYB + WYB - 1 - a); j_a < 0: identity (tau = 0, v = 0)
+  for (int a = 0; a < WYB; ++a)
+    for (int c = a + 1; c < WYB; ++c) {
+      const int ja = jtop - (g * WYB + WYB - 1 - a), jc = jtop - (g * WYB + WYB - 1 - c);
+      double s = 0.0;
+      if (ja >= 0 && jc >= 0)
+        for (int i = lane; i < n; i += 64) s = fma(Vh[(int64_t)ja * lda + i], Vh[(int64_t)jc * lda + i], s);
+      s = wave_sum(s);
+      if (lane == 0) G[a][c] = s;
+    }
+  __syncthreads();
+  if (lane == 0) {
+    for (int a = 0; a < WYB; ++a) {
+      const int ja = jtop - (g * WYB + WYB - 1 - a);
+      const double ta = ja >= 0 ? tt[ja] : 0.0;
+      for (int i = 0; i < WYB; ++i) T[i][a] = 0.0;
+      T[a][a] = ta;
+      for (int i = 0; i < a; ++i) {
+        double s = 0.0;
+        for (int m = i; m < a; ++m) s = fma(T[i][m], G[m][a], s);
+        T[i][a] = -ta * s;
+      }
+    }
+  }
+  __syncthreads();
+  double* out = Tw + b * t_stride + (int64_t)g * WYB * WYB;
+  if (lane < WYB * WYB) out[lane] = T[lane / WYB][lane % WYB];
+}
+
+template <int SEG, int R, int RB, int WYB>
+__global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int k_fill,
+                                                       const double* __restrict__ Tw, int64_t t_stride) {
   constexpr int NP = SEG * R;             // padded order
   constexpr int PER = RB * NP / 256;      // doubles per thread and block
-  static_assert(RB * NP % 256 == 0, "block must divide over the workgroup");
+  constexpr int NG = RB / WYB;            // WY groups per staged block
+  static_assert(RB * NP % 256 == 0 && RB % WYB == 0, "block must divide over the workgroup / into WY groups");
   const TrdDesc& d = desc[blockIdx.y];
   const int n = d.n, k = d.k, kp = w.kp, lda = w.lda;
   const int tid = threadIdx.x;
@@ -850,19 +905,20 @@ __global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict
   const int64_t b = blockIdx.y;
   const double* Z = w.Z + b * w.n_max * kp;
   const double* Vh = w.Vh + b * w.n_max * lda;
-  const double* tt = w.tau + b * w.n_max;
+  const double* Tb = Tw + b * t_stride;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // [2][RB][NP]
-  __shared__ double taus[2][RB];
+  __shared__ double tls[2][NG][WYB * WYB];
   double x[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = seg + SEG * r;
     x[r] = (live && i < n) ? Z[(int64_t)i * kp + c] : 0.0;
   }
-  // block t holds reflectors j = jtop - t RB - q, q = 0..RB-1 (j < 0: identity)
+  // staged block t holds reflectors u = t RB + qq, qq = 0..RB-1 (j = jtop - u < 0: identity)
   const int jtop = n - 2;
   const int nblocks = jtop >= 0 ? (jtop + RB) / RB : 0;
   double stage[PER];
+  double tstage = 0.0;
   auto fetch = [&](int t) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
@@ -870,15 +926,16 @@ __global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict
       const int j = jtop - t * RB - qq;
       stage[u] = (j >= 0 && i < n) ? Vh[(int64_t)j * lda + i] : 0.0;
     }
+    if (tid < NG * WYB * WYB) {
+      const int g = t * NG + tid / (WYB * WYB);
+      tstage = g * WYB <= jtop ? Tb[(int64_t)g * WYB * WYB + tid % (WYB * WYB)] : 0.0;
+    }
   };
   auto commit = [&](int t) {
     double* buf = lds + (t & 1) * RB * NP;
 #pragma unroll
     for (int u = 0; u < PER; ++u) buf[tid + 256 * u] = stage[u];
-    if (tid < RB) {
-      const int j = jtop - t * RB - tid;
-      taus[t & 1][tid] = j >= 0 ? tt[j] : 0.0;
-    }
+    if (tid < NG * WYB * WYB) tls[t & 1][tid / (WYB * WYB)][tid % (WYB * WYB)] = tstage;
   };
   if (nblocks > 0) {
     fetch(0);
@@ -889,20 +946,37 @@ __global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict
     if (t + 1 < nblocks) fetch(t + 1);
     const double* buf = lds + (t & 1) * RB * NP;
 #pragma unroll
-    for (int qq = 0; qq < RB; ++qq) {
-      const double* v = buf + qq * NP + seg;
-      double vr[R];
-      double s = 0.0;
+    for (int gq = 0; gq < NG; ++gq) {
+      // group of WYB reflectors: staged rows gq WYB + q, q = 0..WYB-1; ascending index a = WYB - 1 - q
+      double vr[WYB][R], y[WYB];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        vr[r] = v[SEG * r];
-        s = fma(vr[r], x[r], s);
+      for (int q = 0; q < WYB; ++q) {
+        const double* v = buf + (gq * WYB + q) * NP + seg;
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          vr[q][r] = v[SEG * r];
+          s = fma(vr[q][r], x[r], s);
+        }
+        y[WYB - 1 - q] = s;
       }
 #pragma unroll
-      for (int off = SEG / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      s *= taus[t & 1][qq];
+      for (int off = SEG / 2; off > 0; off >>= 1)
 #pragma unroll
-      for (int r = 0; r < R; ++r) x[r] = fma(-s, vr[r], x[r]);
+        for (int a = 0; a < WYB; ++a) y[a] += __shfl_xor(y[a], off, 64);
+      const double* T = tls[t & 1][gq];
+      double z[WYB];
+#pragma unroll
+      for (int a = 0; a < WYB; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int bb = a; bb < WYB; ++bb) s = fma(T[a * WYB + bb], y[bb], s);
+        z[a] = s;
+      }
+#pragma unroll
+      for (int q = 0; q < WYB; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = fma(-z[WYB - 1 - q], vr[q][r], x[r]);
     }
     if (t + 1 < nblocks) commit(t + 1);  // the other buffer: its readers finished before the last barrier
     __syncthreads();
@@ -1001,7 +1075,7 @@ __global__ void trd_setk_kernel(TrdDesc* __restrict__ desc, RankChunk chunk, int
 // ------------------------------------------------------------------------------------------ host side
 struct TrdLayout {
   int64_t n_max, lda, kp;
-  int64_t off_a, off_vh, off_y, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, total;
+  int64_t off_a, off_vh, off_y, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, total;
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -1028,6 +1102,8 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_piv = take(batch * n_max * l.kp);
   l.off_desc = take(batch * (int64_t)sizeof(TrdDesc));
   l.off_stamps = take(batch * 16 * 8);
+  l.t_stride = (n_max + 8) * 4;  // groups of WYB reflectors, WYB^2 doubles each, WYB <= 4
+  l.off_tw = take(batch * l.t_stride * 8);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -1047,6 +1123,8 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.lu = (double*)(base + l.off_lu);
   w.piv = (unsigned char*)(base + l.off_piv);
   w.stamps = (long long*)(base + l.off_stamps);
+  w.Tw = (double*)(base + l.off_tw);
+  w.t_stride = l.t_stride;
   w.n_max = (int)l.n_max;
   w.lda = (int)l.lda;
   w.kp = (int)l.kp;
@@ -1185,15 +1263,19 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
   const int cols = std::max(kk, k_fill);
   // rows per lane of the back-transform: n <= SEG * R; RB reflectors of SEG * R doubles per LDS block
   const int per32 = (int)ndmps::ceil_div(n_max, 32), per64 = (int)ndmps::ceil_div(n_max, 64);
-#define NDMPS_BACK(SEG, R, RB)                                                                            \
-  hipLaunchKernelGGL((trd_back_kernel<SEG, R, RB>), dim3(ndmps::ceil_div(cols, 256 / SEG), B), dim3(256), \
-                     (size_t)2 * RB * SEG * R * sizeof(double), s, desc, w, k_fill)
-  if (per32 <= 4) NDMPS_BACK(32, 4, 8);
-  else if (per32 <= 8) NDMPS_BACK(32, 8, 8);
-  else if (per32 <= 16) NDMPS_BACK(32, 16, 8);
-  else if (per32 <= 32) NDMPS_BACK(32, 32, 4);
-  else if (per64 <= 32) NDMPS_BACK(64, 32, 2);
-  else NDMPS_BACK(64, 64, 1);
+#define NDMPS_BACK(SEG, R, RB, WYB)                                                                            \
+  do {                                                                                                          \
+    const int groups = (int)ndmps::ceil_div(std::max<int64_t>(n_max - 1, 1), WYB);                               \
+    hipLaunchKernelGGL((trd_wy_kernel<WYB>), dim3(groups, B), dim3(64), 0, s, desc, w, w.Tw, w.t_stride);         \
+    hipLaunchKernelGGL((trd_back_kernel<SEG, R, RB, WYB>), dim3(ndmps::ceil_div(cols, 256 / SEG), B), dim3(256), \
+                       (size_t)2 * RB * SEG * R * sizeof(double), s, desc, w, k_fill, w.Tw, w.t_stride);         \
+  } while (0)
+  if (per32 <= 4) NDMPS_BACK(32, 4, 8, 4);
+  else if (per32 <= 8) NDMPS_BACK(32, 8, 8, 4);
+  else if (per32 <= 16) NDMPS_BACK(32, 16, 8, 4);
+  else if (per32 <= 32) NDMPS_BACK(32, 32, 4, 2);
+  else if (per64 <= 32) NDMPS_BACK(64, 32, 2, 2);
+  else NDMPS_BACK(64, 64, 1, 1);
 #undef NDMPS_BACK
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
