@@ -565,6 +565,143 @@ __device__ __forceinline__ double hash_uniform(unsigned a, unsigned b) {
   return (double)x * (2.0 / 4294967296.0) - 1.0 + 1.1e-10;  // never exactly zero
 }
 
+// ---- 16 x 16 tile products on the f64 MFMA with both operands row-major in LDS (ld doubles per row):
+//   nt: C[i][j] += sum_k X[r0 + i][k0 + k] Y[c0 + j][k0 + k]      nn: C[i][j] += sum_k X[r0 + i][k0 + k] Y[k0 + k][c0 + j]
+// accumulator element r of a lane = C[(lane >> 4) + 4 r][lane & 15]; `sign` -1 subtracts
+__device__ __forceinline__ f64x4 tile_nt(f64x4 acc, const double* X, int r0, const double* Y, int c0, int k0, int ld,
+                                         int lane, double sign) {
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * X[(r0 + li) * ld + k0 + 4 * s4 + lk], Y[(c0 + li) * ld + k0 + 4 * s4 + lk],
+                                               acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f64x4 tile_nn(f64x4 acc, const double* X, int r0, const double* Y, int c0, int k0, int ld,
+                                         int lane, double sign) {
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * X[(r0 + li) * ld + k0 + 4 * s4 + lk], Y[(k0 + 4 * s4 + lk) * ld + c0 + li],
+                                               acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f64x4 tile_load(const double* M, int r0, int c0, int ld, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  f64x4 t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = M[(r0 + lk + 4 * r) * ld + c0 + li];
+  return t;
+}
+__device__ __forceinline__ void tile_store(double* M, int r0, int c0, int ld, int lane, f64x4 t) {
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) M[(r0 + lk + 4 * r) * ld + c0 + li] = t[r];
+}
+
+// Blocked Cholesky S = L L^T and L^-1 for k16 <= 64 in LDS (S, then L, in the lower triangle of Ls; L^-1 in Li,
+// both [k16][ld]); 16 x 16 tiles, diagonal tiles by one wave in registers (lane = row, shuffles broadcast the
+// pivots), panels / trailing updates / inverse blocks on the f64 MFMA, three barriers per tile column.  Eight
+// waves.  kk: true order (rows and columns >= kk are padding: treated as identity).  Returns false on breakdown.
+__device__ bool chol_inv_blocked(double* Ls, double* Li, int k16, int kk, int ld, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int nt = k16 / 16;
+  __shared__ int bad;
+  if (tid == 0) bad = 0;
+  for (int e = tid; e < k16 * ld; e += 512) Li[e] = 0.0;
+  // padding: unit diagonal, zero elsewhere (the Gram of the zero pad columns is zero)
+  for (int e = tid; e < k16; e += 512)
+    if (e >= kk) Ls[e * ld + e] = 1.0;
+  __syncthreads();
+  for (int J = 0; J < nt; ++J) {
+    const int j0 = 16 * J;
+    if (wave == 0) {
+      // ---- diagonal tile: lane i < 16 holds row i of S_JJ
+      double row[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) row[c] = lane < 16 ? Ls[(j0 + lane) * ld + j0 + c] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = __shfl(row[c], c, 64);
+        double rs = 1.0;
+        if (piv > 0.0) rs = fast_rsqrt<2>(piv);
+        else if (lane == 0) bad = 1;
+        const double lc = lane == c ? piv * rs : (lane > c ? row[c] * rs : 0.0);
+        row[c] = lc;
+#pragma unroll
+        for (int cc = c + 1; cc < 16; ++cc) {
+          const double lcc = __shfl(lc, cc, 64);
+          row[cc] = fma(-lc, lcc, row[cc]);
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Ls[(j0 + lane) * ld + j0 + c] = row[c];  // lower triangle, zeros above
+      }
+      // ---- its inverse: lane c < 16 makes column c by forward substitution (rows of L broadcast by shuffle)
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double sum = lane == i ? 1.0 : 0.0;
+#pragma unroll
+        for (int pz = 0; pz < i; ++pz) {
+          const double lip = __shfl(row[pz], i, 64);  // L[i][pz]
+          sum = fma(-lip, x[pz], sum);
+        }
+        const double lii = __shfl(row[i], i, 64);
+        x[i] = lane <= i ? sum * fast_rcp<2>(lii) : 0.0;
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Li[(j0 + i) * ld + j0 + lane] = x[i];
+      }
+    }
+    __syncthreads();
+    // ---- panel: L_IJ = S_IJ Linv_JJ^T  for tiles I > J, one wave each
+    for (int I = J + 1 + wave; I < nt; I += 8) {
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      acc = tile_nt(acc, Ls, 16 * I, Li, j0, j0, ld, lane, 1.0);
+      tile_store(Ls, 16 * I, j0, ld, lane, acc);  // the wave has read its whole tile (operands) before this store
+    }
+    __syncthreads();
+    // ---- trailing update: S_IK -= L_IJ L_KJ^T  for J < K <= I
+    {
+      int t = 0;
+      for (int I = J + 1; I < nt; ++I)
+        for (int K = J + 1; K <= I; ++K, ++t)
+          if (t % 8 == wave) {
+            f64x4 acc = tile_load(Ls, 16 * I, 16 * K, ld, lane);
+            acc = tile_nt(acc, Ls, 16 * I, Ls, 16 * K, j0, ld, lane, -1.0);
+            tile_store(Ls, 16 * I, 16 * K, ld, lane, acc);
+          }
+    }
+    __syncthreads();
+  }
+  // ---- off-diagonal blocks of L^-1, block row by block row: Linv_IJ = -Linv_II (sum_{J <= K < I} L_IK Linv_KJ)
+  for (int I = 1; I < nt; ++I) {
+    f64x4 tmp[1];
+    const int J = wave;  // at most 3 block columns: one wave each
+    if (J < I) {
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int K = J; K < I; ++K) acc = tile_nn(acc, Ls, 16 * I, Li, 16 * J, 16 * K, ld, lane, 1.0);
+      tmp[0] = acc;
+      // through LDS to become an operand: the tile (I, J) of Li is still zero and unused by the other waves
+      tile_store(Li, 16 * I, 16 * J, ld, lane, acc);
+    }
+    __syncthreads();
+    if (J < I) {
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      // Linv_II (rows 16 I.., cols 16 I..) times the tile just stored at (I, J): nn with X = Li diag, Y = Li
+      acc = tile_nn(acc, Li, 16 * I, Li, 16 * J, 16 * I, ld, lane, -1.0);
+      tmp[0] = acc;
+    }
+    __syncthreads();
+    if (J < I) tile_store(Li, 16 * I, 16 * J, ld, lane, tmp[0]);
+    __syncthreads();
+  }
+  return bad == 0;
+}
+
 // One workgroup (512 threads) per matrix.  Threads c < k factor T - lam_c I (pivoted, dgttrf order) and solve
 // twice from a random start; no orthogonalisation in between (columns of a numerically multiple eigenvalue
 // stay independent because their starts are), then the whole workgroup orthonormalises the block twice:
@@ -577,7 +714,7 @@ __device__ __forceinline__ double hash_uniform(unsigned a, unsigned b) {
 __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ desc, TrdWork w) {
   TrdDesc& d = desc[blockIdx.y];
   const int n = d.n, k = d.k, kp = w.kp;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int64_t b = blockIdx.y;
   const double* dd = w.d + b * w.n_max;
   const double* ee = w.e + b * w.n_max;
@@ -589,8 +726,6 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   double* DU2 = DU + plane;
   unsigned char* PV = w.piv + b * plane;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* Ls = lds;  // [k16][k16 + 1] Cholesky factor
-  const int k16 = (k + 15) & ~15, ldl = k16 + 1;
   const double bound = w.bound[b];
   const double inv = bound > 0.0 ? 1.0 / bound : 0.0;
   constexpr double kEps = 2.220446049250313e-16;
@@ -647,90 +782,144 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
     }
     if (di == 0.0) di = kEps;
     DI[(int64_t)(n - 1) * kp + c] = fast_rcp<2>(di);
+    Z[(int64_t)(n - 1) * kp + c] = xi;  // last component of the fused forward sweep
     if (tid == 0) stamp[1] = wall_clock64();
+  }
+  __syncthreads();  // the factors and the first forward sweep are visible to the whole workgroup
 
-    for (int it = 0; it < 2; ++it) {
-      if (it > 0) {
-        // ---- forward sweep of the second solve: x <- L^-1 P x, operands one chunk ahead
+  // ---- the remaining sweeps: back substitution, forward sweep, back substitution.  Each is a recurrence over
+  // the rows on k lanes whose operands (three or four values per row and lane) sit in global memory: a lone
+  // lane fetching them a few rows ahead pays a memory round trip every few rows (78 us per sweep of 512 rows).
+  // Here the WHOLE workgroup streams them through a double-buffered LDS ring, two blocks of SB rows ahead of the
+  // lanes that run the recurrence, with 16-byte-coalesced loads.
+  {
+    const int SB = kp <= 64 ? 32 : 16;
+    const int per_arr = SB * kp;               // doubles per operand array and block
+    double* ring = lds;                         // [2][4][per_arr]
+    double st0[4][4], st1[4][4];                // two register stages x 4 arrays x <= 4 elements per thread
+    const bool solver = tid < k;
+    const int c = tid;
+    double xi = solver ? Z[(int64_t)(n - 1) * kp + c] : 0.0;  // last component of the fused first forward sweep
+    for (int sweep = 0; sweep < 3; ++sweep) {
+      const bool backward = sweep != 1;
+      const int rows = n - 1;                   // both recurrences visit rows 0 .. n-2
+      const int nblk = (rows + SB - 1) / SB;
+      // row visited at position s of block blk (may be out of range: < 0 or > n-2)
+      auto row_of = [&](int blk, int s2) { return backward ? (n - 2) - blk * SB - s2 : blk * SB + s2; };
+      auto fetch = [&](int blk, double (&dst)[4][4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = tid + 512 * u;
+          const int s2 = e / kp, cc = e % kp;
+          const int r = row_of(blk, s2);
+          const bool ok = e < per_arr && blk < nblk && r >= 0 && r <= n - 2;
+          const int64_t o = (int64_t)(ok ? r : 0) * kp + cc;
+          if (backward) {
+            dst[0][u] = ok ? Z[o] : 0.0;
+            dst[1][u] = ok ? DU[o] : 0.0;
+            dst[2][u] = ok ? DU2[o] : 0.0;
+            dst[3][u] = ok ? DI[o] : 1.0;
+          } else {
+            dst[0][u] = ok ? Z[o + kp] : 0.0;
+            dst[1][u] = ok ? DL[o] : 0.0;
+            dst[2][u] = (ok && PV[o] != 0) ? 1.0 : 0.0;
+            dst[3][u] = 0.0;
+          }
+        }
+      };
+      auto commit = [&](int blk, const double (&src)[4][4]) {
+        double* buf = ring + (blk & 1) * 4 * per_arr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = tid + 512 * u;
+          if (e < per_arr) {
+#pragma unroll
+            for (int a2 = 0; a2 < 4; ++a2) buf[a2 * per_arr + e] = src[a2][u];
+          }
+        }
+      };
+      double x1 = 0.0, x2 = 0.0;
+      if (backward) {
+        if (solver) {
+          x1 = xi * DI[(int64_t)(n - 1) * kp + c];
+          Z[(int64_t)(n - 1) * kp + c] = x1;
+        }
+      } else if (solver) {
         xi = Z[c];
-        double zn[CH], fn[CH];
-        bool sn[CH];
-        auto fetch_f = [&](int i0) {
+      }
+      __syncthreads();  // the previous sweep's stores are visible; the ring is free
+      fetch(0, st0);
+      fetch(1, st1);
+      commit(0, st0);
+      __syncthreads();
+      // The stage holding block blk + 1 (fetched two iterations ago) is parked in the other LDS buffer, then
+      // reused for block blk + 2.  The stages are named, not indexed: a run-time index would put them in scratch.
+      auto iteration = [&](int blk, double (&parked)[4][4], double (&refill)[4][4]) {
+        if (blk + 1 < nblk) commit(blk + 1, parked);
+        fetch(blk + 2, refill);
+        if (solver) {
+          const double* buf = ring + (blk & 1) * 4 * per_arr + c;
+          for (int s0 = 0; s0 < SB; s0 += CH) {  // eight rows' operands out of LDS, then eight steps of the chain
+            double o0[CH], o1[CH], o2[CH], o3[CH];
 #pragma unroll
-          for (int u = 0; u < CH; ++u) {
-            const int64_t o = (int64_t)min(i0 + u, n - 2) * kp + c;
-            zn[u] = Z[o + kp];
-            fn[u] = DL[o];
-            sn[u] = PV[o] != 0;
-          }
-        };
-        if (n > 1) fetch_f(0);
-        for (int i0 = 0; i0 + 1 < n; i0 += CH) {
-          double zl[CH], fl[CH];
-          bool sw[CH];
+            for (int u = 0; u < CH; ++u) {
+              const int e = (s0 + u) * kp;
+              o0[u] = buf[e];
+              o1[u] = buf[per_arr + e];
+              o2[u] = buf[2 * per_arr + e];
+              o3[u] = buf[3 * per_arr + e];
+            }
 #pragma unroll
-          for (int u = 0; u < CH; ++u) {
-            zl[u] = zn[u];
-            fl[u] = fn[u];
-            sw[u] = sn[u];
-          }
-          if (i0 + CH + 1 < n) fetch_f(i0 + CH);
-#pragma unroll
-          for (int u = 0; u < CH; ++u) {
-            const int i = i0 + u;
-            if (i + 1 < n) {
-              const double top = sw[u] ? zl[u] : xi;
-              const double bot = sw[u] ? xi : zl[u];
-              Z[(int64_t)i * kp + c] = top;
-              xi = fma(-fl[u], top, bot);
+            for (int u = 0; u < CH; ++u) {
+              const int r = row_of(blk, s0 + u);
+              const bool in = r >= 0 && r <= n - 2;
+              if (backward) {
+                const double x0 = (o0[u] - o1[u] * x1 - o2[u] * x2) * o3[u];
+                if (in) {
+                  Z[(int64_t)r * kp + c] = x0;
+                  x2 = x1;
+                  x1 = x0;
+                }
+              } else {
+                const bool sw = o2[u] != 0.0;
+                const double top = sw ? o0[u] : xi, bot = sw ? xi : o0[u];
+                if (in) {
+                  Z[(int64_t)r * kp + c] = top;
+                  xi = fma(-o1[u], top, bot);
+                }
+              }
             }
           }
         }
-      }
-      // ---- back substitution with U (d, du, du2), operands one chunk ahead; the result grows by ~1/eps
-      //      per solve and is not rescaled (two solves stay far inside the fp64 range)
-      double x2 = 0.0, x1 = xi * DI[(int64_t)(n - 1) * kp + c];
-      Z[(int64_t)(n - 1) * kp + c] = x1;
-      double zn[CH], un_[CH], u2n[CH], in_[CH];
-      auto fetch_b = [&](int i0) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int64_t o = (int64_t)max(i0 - u, 0) * kp + c;
-          zn[u] = Z[o];
-          un_[u] = DU[o];
-          u2n[u] = DU2[o];
-          in_[u] = DI[o];
-        }
+        __syncthreads();
       };
-      if (n > 1) fetch_b(n - 2);
-      for (int i0 = n - 2; i0 >= 0; i0 -= CH) {
-        double zl[CH], ul[CH], u2l[CH], il[CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          zl[u] = zn[u];
-          ul[u] = un_[u];
-          u2l[u] = u2n[u];
-          il[u] = in_[u];
-        }
-        if (i0 - CH >= 0) fetch_b(i0 - CH);
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int i = i0 - u;
-          if (i >= 0) {
-            const double x0 = (zl[u] - ul[u] * x1 - u2l[u] * x2) * il[u];
-            Z[(int64_t)i * kp + c] = x0;
-            x2 = x1;
-            x1 = x0;
-          }
-        }
+      for (int blk = 0; blk < nblk; blk += 2) {
+        iteration(blk, st1, st0);
+        if (blk + 1 < nblk) iteration(blk + 1, st0, st1);
       }
     }
   }
   // pad columns of the block stay zero
   if (k < kp)
     for (int e = tid; e < n * (kp - k); e += 512) Z[(int64_t)(e / (kp - k)) * kp + k + e % (kp - k)] = 0.0;
-  __syncthreads();
   if (tid == 0) stamp[2] = wall_clock64();
+}
+
+// Orthonormalisation of the n x k block Z (its own kernel: the recurrences above and the products below have
+// very different register needs, one kernel for both spilled 119 VGPRs).  One workgroup (512 threads) per matrix.
+// FAST: k <= 64 (blocked Cholesky, explicit L^-1, products on the MFMA); otherwise the column-by-column
+// Cholesky and a row-by-row triangular solve (any k <= 128; only BASELINE config 5 gets there).
+template <bool FAST>
+__global__ void __launch_bounds__(512) trd_ortho_kernel(TrdDesc* __restrict__ desc, TrdWork w) {
+  TrdDesc& d = desc[blockIdx.y];
+  const int n = d.n, k = d.k, kp = w.kp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.y;
+  double* Z = w.Z + b * w.n_max * kp;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Ls = lds;  // [k16][k16 + 1] Cholesky factor
+  const int k16 = (k + 15) & ~15, ldl = k16 + 1;
+  long long* stamp = w.stamps + b * 16;
 
   for (int pass = 0; pass < 2; ++pass) {
     // ---- S = Z^T Z, 16 x 16 tiles (ta <= tb) on f64 MFMA, operands straight from global / L2,
@@ -769,6 +958,38 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
     }
     __syncthreads();
     if (tid == 0) stamp[3 + 3 * pass] = wall_clock64();
+    if constexpr (FAST) {
+      // ---- fast path: blocked Cholesky + explicit L^-1 in LDS, then Z <- Z L^-T as a product on the MFMA
+      double* Li = lds + k16 * ldl;
+      if (!chol_inv_blocked(Ls, Li, k16, k, ldl, tid) && tid == 0) d.status = 1;
+      if (tid == 0) stamp[4 + 3 * pass] = wall_clock64();
+      // one wave per 16-row block of Z: all its operands are read before anything is written back
+      for (int rt = wave; rt * 16 < n; rt += 8) {
+        const int i0 = 16 * rt, li = lane & 15, lk = lane >> 4;
+        double av[16];
+        const bool row_ok = i0 + li < n;
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+          const int col = 4 * s4 + lk;
+          av[s4] = (row_ok && col < k16) ? Z[(int64_t)(i0 + li) * kp + col] : 0.0;
+        }
+        for (int ct = 0; ct < k16 / 16; ++ct) {
+          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+          // columns a <= c only: L^-1 is lower triangular
+#pragma unroll
+          for (int s4 = 0; s4 < 16; ++s4)
+            if (4 * s4 < 16 * (ct + 1) && 4 * s4 < k16)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], Li[(16 * ct + li) * ldl + 4 * s4 + lk], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = i0 + lk + 4 * r, cc = 16 * ct + li;
+            if (i < n && cc < k) Z[(int64_t)i * kp + cc] = acc[r];
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) stamp[5 + 3 * pass] = wall_clock64();
+    } else {
     // ---- Cholesky S = L L^T, left-looking by columns (lower triangle of Ls), rows >= k untouched
     for (int jc = 0; jc < k; ++jc) {
       double v = 0.0;
@@ -822,6 +1043,7 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
     }
     __syncthreads();
     if (tid == 0) stamp[5 + 3 * pass] = wall_clock64();
+    }
   }
 }
 
@@ -1151,6 +1373,10 @@ int trd_opt_in() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxN * (int)sizeof(RowVec)));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_invit_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_ortho_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_ortho_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
   done[dev] = true;
   return NDMPS_OK;
 }
@@ -1258,8 +1484,12 @@ namespace {
 int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* desc, const TrdWork& w, hipStream_t s) {
   const unsigned B = (unsigned)batch;
   const int k16 = (kk + 15) & ~15;
-  hipLaunchKernelGGL(trd_invit_kernel, dim3(1, B), dim3(512), std::max((size_t)k16 * (k16 + 1) * 8, (size_t)n_max * 16), s, desc,
-                     w);
+  hipLaunchKernelGGL(trd_invit_kernel, dim3(1, B), dim3(512),
+                     std::max((size_t)n_max * 16, (size_t)2 * 4 * (w.kp <= 64 ? 32 : 16) * w.kp * 8), s, desc, w);
+  if (k16 <= 64)
+    hipLaunchKernelGGL(trd_ortho_kernel<true>, dim3(1, B), dim3(512), (size_t)2 * k16 * (k16 + 1) * 8, s, desc, w);
+  else
+    hipLaunchKernelGGL(trd_ortho_kernel<false>, dim3(1, B), dim3(512), (size_t)k16 * (k16 + 1) * 8, s, desc, w);
   const int cols = std::max(kk, k_fill);
   // rows per lane of the back-transform: n <= SEG * R; RB reflectors of SEG * R doubles per LDS block
   const int per32 = (int)ndmps::ceil_div(n_max, 32), per64 = (int)ndmps::ceil_div(n_max, 64);
