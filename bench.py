@@ -229,7 +229,7 @@ def main():
 
     ms, launches, nbytes = C.c_double(), C.c_int64(), C.c_int64()
     _lib.check(lib.ndmps_profile_collect(1, C.byref(ms), C.byref(launches), C.byref(nbytes)))
-    col_us = ms.value * 1e3 / max(launches.value, 1)
+    col_us = max(ms.value * 1e3 / max(launches.value, 1), 1e-9)
     col_bytes = nbytes.value / max(launches.value, 1)
     achieved = col_bytes / (col_us * 1e-6) / 1e9 if launches.value else float("nan")
     traffic, pmc_entry = pmc_traffic("trd_column_kernel")
@@ -279,7 +279,7 @@ def main():
         torch.cuda.synchronize()
         _lib.check(lib.ndmps_profile_enable(0))
         _lib.check(lib.ndmps_profile_collect(1, C.byref(ms), C.byref(launches), C.byref(nbytes)))
-        iso_us = ms.value * 1e3 / max(launches.value, 1)
+        iso_us = max(ms.value * 1e3 / max(launches.value, 1), 1e-9)
         iso_bytes = nbytes.value / max(launches.value, 1)
         roofline["isolated"] = {
             "workload": f"{nb_eig} x ({n_eig} x {n_eig}) fp64 Gram matrices, one stream, nothing else on the GPU",

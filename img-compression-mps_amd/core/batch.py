@@ -101,7 +101,7 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
             stream.wait_event(ready)  # inputs produced on the caller's stream
             objs = NDMPS.from_tensors([tensor_list[i] for i in idx], norm=norm, mode=mode, max_bond=max_bond,
                                       cutoff=cutoff)
-            recs = [o.to_tensor(as_torch=True) for o in objs] if reconstruct else None
+            recs = NDMPS.to_tensors(objs, as_torch=True) if reconstruct else None
         # host-side completion: a device-side wait on the caller's stream would sit in whichever
         # hardware queue that stream shares with a group and hold that group's next launches behind it
         stream.synchronize()
@@ -124,7 +124,9 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
 
 def conv_to_tensors(mps_list: Sequence, as_torch: bool = False):
     """benchmark.py:80-100: reconstruct every NDMPS of the (local) list."""
-    return [m.to_tensor(as_torch=as_torch) for m in mps_list]
+    from .ndmps import NDMPS
+
+    return NDMPS.to_tensors(mps_list, as_torch=as_torch)
 
 
 def compress_list(mps_list: Sequence, cutoff: float, max_bond=None) -> None:

@@ -138,7 +138,10 @@ class _Site:
 class DeviceMPS:
     """Open-boundary MPS with fp32 cores ``(chi_i, d_i, chi_{i+1})`` in HBM."""
 
-    def __init__(self, cores):
+    def __init__(self, cores, _trusted=False):
+        if _trusted:  # cores made by the sweep: contiguous 3-D views already
+            self.cores = list(cores)
+            return
         self.cores = [c.contiguous() for c in cores]
         for c in self.cores:
             if c.dim() != 3:

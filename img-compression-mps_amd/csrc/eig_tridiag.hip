@@ -49,10 +49,19 @@ struct TrdDesc {       // one per matrix (device array), blockIdx.y selects it
   int pad;
 };
 
+struct TeamSync {
+  unsigned long long count;  // arrivals of the matrix's workgroups, monotonic over the columns
+  int abort;                 // a wait ran out of time: every workgroup of the team leaves
+  int pad[317];              // 1280 bytes apart: the counters of a batch sit in different memory channels (the
+                             // arrivals and polls of adjacent counters queued behind each other: time ~ batch)
+};
+
 struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   double* A;           // [B][n_max][lda] working copy, trailing part updated in place
   double* Vh;          // [B][n_max][lda] reflector j in row j (zeros up to j, 1 at j + 1)
   double* y;           // [B][2][lda] matrix-vector products, by parity of the column
+  double* xc;          // [B][2][lda] team kernel: column j of the trailing matrix, by parity of j
+  TeamSync* sync;      // [B] team kernel: arrival counter of the matrix's workgroups
   double* tau;         // [B][n_max]
   double* d;           // [B][n_max] diagonal of T
   double* e;           // [B][n_max] sub-diagonal of T
@@ -321,6 +330,280 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
   __syncthreads();
   if (tid < CW && c0 + tid < lda)
     ybuf[(j & 1) * lda + c0 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+}
+
+// ----------------------------------------------------------------------------------------- team kernel
+// The same reduction with the trailing matrix RESIDENT IN REGISTERS: one launch for all columns 0 .. n - 129
+// of every matrix (n <= 512).  Workgroup (r, b) keeps columns [32 r, 32 r + 32) of matrix b over all 512 rows
+// in its registers (16 tiles of 4 doubles per lane = 128 KB per workgroup, two workgroups per CU), so the
+// column launches' traffic -- one read and one write of the trailing matrix per column, the bound of
+// trd_column_kernel -- disappears; what remains per column is the exchange the kernel boundary
+// used to provide: every workgroup publishes its 32 entries of y_j = A v_j, the owner of column j + 1 publishes
+// that column (row j + 1 by symmetry), the matrix's workgroups meet at a counter in global memory and each
+// reads the two n-vectors back.  Exchange data moves with agent-scope atomic stores / loads (write-through,
+// never served from a stale L2 line of another XCD); release / acquire fences order them around the counter.
+//
+// The workgroups of a matrix (its team, 16 at n = 512) must be resident together.  The dispatcher places
+// workgroups in grid order and a team is 16 consecutive ones, so the teams at the front of the grid are always
+// complete and their exit frees the slots the next ones wait for: a grid larger than the GPU is fine.  Two team
+// kernels from different streams could starve each other (each holding slots the other's partial teams wait
+// for), so the host chains them by an event: at most one is in flight per device.  Ordinary kernels sharing
+// the GPU end by themselves.  Every wait is bounded all the same: after kTeamSpinTicks the waiting workgroup
+// raises the team's abort flag, every member leaves at its next wait and status 2 reaches the host.
+//
+// Arithmetic: the prologue and the per-element update are those of trd_column_kernel (same redundant,
+// bit-identical O(n) part in every workgroup); only the association of the column sums differs (rows are
+// dealt to lanes independently of j).
+constexpr long long kTeamSpinTicks = 300000000LL;  // 3 s of the 100 MHz wall clock
+
+__device__ __forceinline__ double team_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void team_store(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NR>
+__global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w) {
+  constexpr int CW = 32;             // columns per workgroup
+  constexpr int LPR = 8;             // lanes per row, 4 columns (32 bytes) each
+  constexpr int RPW = 64 / LPR;      // rows per wave instruction
+  constexpr int RPI = 4 * RPW;       // rows per tile of the workgroup
+  constexpr int NT = 512 / RPI;      // tiles per lane: 512 rows
+  TrdDesc& d = desc[blockIdx.y];
+  const int n = d.n;
+  const int J = n - kTail;           // columns 0 .. J - 1 are reduced here, the rest by the tail kernel
+  const int c0 = blockIdx.x * CW;
+  if (J <= 0 || c0 >= n) return;
+  const int nblk = (n + CW - 1) / CW;
+  const int j_last = min(J - 1, c0 + CW - 2);  // the block's columns are finished once j + 1 >= c0 + CW
+  const int lda = w.lda;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.y;
+  double* A = w.A + b * w.n_max * lda;
+  double* Vh = w.Vh + b * w.n_max * lda;
+  double* ybuf = w.y + b * 2 * lda;
+  double* xc = w.xc + b * 2 * lda;
+  TeamSync* sync = w.sync + b;
+  __shared__ RowVec rv[512];
+  __shared__ double red_a[4], red_b[4];
+  __shared__ double part[4][CW];
+  __shared__ int go;
+
+  const int q = lane / LPR, p = lane % LPR;
+  const int c = c0 + 4 * p;
+  const int row0 = RPW * wave + q;
+  double a[NT][4];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int i = row0 + RPI * u;
+    double2 lo = make_double2(0.0, 0.0), hi = lo;
+    if (i < n) {  // lda is even; columns >= n up to lda hold zeros
+      if (c < lda) lo = *reinterpret_cast<const double2*>(A + (int64_t)i * lda + c);
+      if (c + 2 < lda) hi = *reinterpret_cast<const double2*>(A + (int64_t)i * lda + c + 2);
+    }
+    a[u][0] = lo.x;
+    a[u][1] = lo.y;
+    a[u][2] = hi.x;
+    a[u][3] = hi.y;
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {  // rows beyond the order never change: zero operands
+    const int i = tid + 256 * r;
+    if (i >= n) {
+      RowVec z;
+      z.vp = z.wp = z.vj = z.pad = 0.0;
+      rv[i] = z;
+    }
+  }
+  double vv[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) vv[r] = 0.0;
+  double taup = 0.0;
+  unsigned long long target = 0;
+  __syncthreads();
+
+  for (int j = 0; j <= j_last; ++j) {
+    // ---- operands of the prologue: y of step j - 1 and column j (both published before the last meeting)
+    double yv[NR], rj[NR];
+    double y_j = 0.0, y_j1 = 0.0, v_j1 = 0.0, r_j1;
+    if (j >= 1) {
+      const double* yprev = ybuf + ((j - 1) & 1) * lda;
+      const double* xcol = xc + (j & 1) * lda;
+      y_j = team_load(yprev + j);
+      y_j1 = team_load(yprev + j + 1);
+      r_j1 = team_load(xcol + j + 1);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int i = tid + 256 * r;
+        const bool in = i >= j && i < n;
+        yv[r] = in ? team_load(yprev + i) : 0.0;
+        rj[r] = in ? team_load(xcol + i) : 0.0;
+      }
+      v_j1 = rv[j + 1].vj;  // still the reflector of step j - 1
+    } else {
+      r_j1 = A[1];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int i = tid + 256 * r;
+        yv[r] = 0.0;
+        rj[r] = i < n ? A[i] : 0.0;
+      }
+    }
+    // ---- prologue a: w' of step j - 1
+    double dot = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) dot = fma(yv[r], vv[r], dot);
+    dot = wave_sum(dot);
+    if (lane == 0) red_a[wave] = dot;
+    __syncthreads();
+    dot = (red_a[0] + red_a[1]) + (red_a[2] + red_a[3]);
+    const double al = 0.5 * taup * taup * dot;
+    const double wpj = taup * y_j - al;  // v'[j] = 1
+    // ---- prologue b: row j with the update applied; x = row[j + 1:], sigma = |x[1:]|^2
+    double wq[NR];
+    double sigma = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int i = tid + 256 * r;
+      wq[r] = taup * yv[r] - al * vv[r];
+      rj[r] -= wq[r] + wpj * vv[r];
+      if (i > j + 1 && i < n) sigma = fma(rj[r], rj[r], sigma);
+    }
+    sigma = wave_sum(sigma);
+    if (lane == 0) red_b[wave] = sigma;
+    __syncthreads();
+    sigma = (red_b[0] + red_b[1]) + (red_b[2] + red_b[3]);
+    const double alpha = r_j1 - ((taup * y_j1 - al * v_j1) + wpj * v_j1);
+    double beta, tau, scale;
+    householder(alpha, sigma, beta, tau, scale);
+    const bool writer = (int)blockIdx.x == (j + 1) / CW;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int i = tid + 256 * r;
+      if (i < n) {
+        const double v = i > j + 1 ? rj[r] * scale : (i == j + 1 ? 1.0 : 0.0);
+        RowVec rec;
+        rec.vp = vv[r];
+        rec.wp = wq[r];
+        rec.vj = v;
+        rec.pad = 0.0;
+        rv[i] = rec;
+        vv[r] = v;
+        if (writer) Vh[(int64_t)j * lda + i] = v;
+        if (writer && i == j) {
+          w.d[b * w.n_max + j] = rj[r];
+          w.e[b * w.n_max + j] = beta;
+          w.tau[b * w.n_max + j] = tau;
+        }
+      } else if (writer && i < lda) {
+        Vh[(int64_t)j * lda + i] = 0.0;
+      }
+    }
+    taup = tau;
+    __syncthreads();
+
+    // ---- body: pending update applied in the registers, column sums with the new reflector
+    double wc[4], vc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = min(c + k, 511);  // records of columns >= n are zero
+      wc[k] = rv[cc].wp;
+      vc[k] = rv[cc].vp;
+    }
+    const int u0 = (j + 1) / RPI;  // tiles made of finished rows only
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      if (u >= u0) {
+        const RowVec rec = rv[row0 + RPI * u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          a[u][k] -= fma(rec.vp, wc[k], rec.wp * vc[k]);
+          acc[k] = fma(a[u][k], rec.vj, acc[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+    if (q == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) part[wave][4 * p + k] = acc[k];
+    }
+    __syncthreads();
+    if (tid < CW && c0 + tid < lda)
+      team_store(ybuf + (j & 1) * lda + c0 + tid, (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+    if (j + 1 >= J) break;  // the tail kernel continues from the stored matrix
+    // ---- column j + 1 of the updated matrix, by its owner
+    if ((int)blockIdx.x == (j + 1) / CW) {
+      const int kk = j + 1 - c0;
+      if (p == kk / 4) {
+        double* out = xc + ((j + 1) & 1) * lda;
+        // one unrolled copy per column slot: a run-time register index would send the tiles to scratch
+#define NDMPS_TEAM_PUBLISH(KS)                                          \
+  _Pragma("unroll") for (int u = 0; u < NT; ++u) {                      \
+    const int i = row0 + RPI * u;                                       \
+    if (u >= u0 && i > j && i < n) team_store(out + i, a[u][KS]);       \
+  }
+        switch (kk % 4) {
+          case 0: NDMPS_TEAM_PUBLISH(0) break;
+          case 1: NDMPS_TEAM_PUBLISH(1) break;
+          case 2: NDMPS_TEAM_PUBLISH(2) break;
+          default: NDMPS_TEAM_PUBLISH(3) break;
+        }
+#undef NDMPS_TEAM_PUBLISH
+      }
+    }
+    // ---- meeting of the matrix's workgroups (a block on its last column only announces itself)
+    target += (unsigned long long)(nblk - (j + 1) / CW);
+    // exchange data are write-through atomic stores: once acknowledged (workgroup-scope release = wait for the
+    // memory counters) they are visible to the agent-scope loads of the other workgroups; no L2 write-back /
+    // invalidate, which would also flush what concurrent kernels of other streams keep there
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(&sync->count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int ok = 1;
+      if (j < j_last) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&sync->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (__hip_atomic_load(&sync->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            ok = 0;
+            break;
+          }
+          if (wall_clock64() - t0 > kTeamSpinTicks) {
+            __hip_atomic_store(&sync->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d.status = 2;
+            ok = 0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      go = ok;
+    }
+    __syncthreads();
+    if (!go) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+
+  // ---- hand-over to the tail kernel: the trailing block as the column launches would have left it (updates
+  //      through J - 2 applied, step J - 1 pending in y / Vh / tau)
+  if (j_last == J - 1) {
+    const int u0 = J / RPI;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int i = row0 + RPI * u;
+      if (u >= u0 && i < n) {
+        if (c < lda) *reinterpret_cast<double2*>(A + (int64_t)i * lda + c) = make_double2(a[u][0], a[u][1]);
+        if (c + 2 < lda) *reinterpret_cast<double2*>(A + (int64_t)i * lda + c + 2) = make_double2(a[u][2], a[u][3]);
+      }
+    }
+  }
 }
 
 // --------------------------------------------------------------------------------------- tail kernel
@@ -1268,7 +1551,7 @@ trd_rank_kernel(TrdDesc* __restrict__ desc, int k_cap, double cutoff, int* __res
   if (threadIdx.x == 0) {
     const int k = min(max(cnt, 1), kk);
     d.k = k;
-    d.status = 0;
+    if (d.status != 2) d.status = 0;  // 2: the team kernel gave up (sticky)
     ranks[blockIdx.x] = k;
   }
 }
@@ -1282,22 +1565,27 @@ struct DescChunk {
 struct RankChunk {
   int v[256];
 };
-__global__ void trd_setdesc_kernel(TrdDesc* __restrict__ desc, DescChunk chunk, int base, int count) {
+__global__ void trd_setdesc_kernel(TrdDesc* __restrict__ desc, DescChunk chunk, int base, int count,
+                                   TeamSync* __restrict__ sync) {
   const int t = threadIdx.x;
-  if (t < count) desc[base + t] = chunk.v[t];
+  if (t < count) {
+    desc[base + t] = chunk.v[t];
+    sync[base + t].count = 0;
+    sync[base + t].abort = 0;
+  }
 }
 __global__ void trd_setk_kernel(TrdDesc* __restrict__ desc, RankChunk chunk, int base, int count) {
   const int t = threadIdx.x;
   if (t < count) {
     desc[base + t].k = chunk.v[t];
-    desc[base + t].status = 0;
+    if (desc[base + t].status != 2) desc[base + t].status = 0;  // 2: the team kernel gave up (sticky)
   }
 }
 
 // ------------------------------------------------------------------------------------------ host side
 struct TrdLayout {
   int64_t n_max, lda, kp;
-  int64_t off_a, off_vh, off_y, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, total;
+  int64_t off_a, off_vh, off_y, off_xc, off_sync, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, total;
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -1314,6 +1602,8 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_a = take(batch * n_max * l.lda * 8);
   l.off_vh = take(batch * n_max * l.lda * 8);
   l.off_y = take(batch * 2 * l.lda * 8);
+  l.off_xc = take(batch * 2 * l.lda * 8);
+  l.off_sync = take(batch * (int64_t)sizeof(TeamSync));
   l.off_tau = take(batch * n_max * 8);
   l.off_d = take(batch * n_max * 8);
   l.off_e = take(batch * n_max * 8);
@@ -1336,6 +1626,8 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.A = (double*)(base + l.off_a);
   w.Vh = (double*)(base + l.off_vh);
   w.y = (double*)(base + l.off_y);
+  w.xc = (double*)(base + l.off_xc);
+  w.sync = (TeamSync*)(base + l.off_sync);
   w.tau = (double*)(base + l.off_tau);
   w.d = (double*)(base + l.off_d);
   w.e = (double*)(base + l.off_e);
@@ -1378,6 +1670,28 @@ int trd_opt_in() {
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_ortho_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
   done[dev] = true;
+  return NDMPS_OK;
+}
+
+// At most one team kernel in flight per device (see trd_team_kernel): the launch waits for the previous one's
+// event on whatever stream it ran.
+template <typename F>
+int team_launch(hipStream_t s, F&& launch) {
+  static std::mutex mu;
+  static hipEvent_t ev[64];
+  static bool have[64] = {};
+  int dev = 0;
+  NDMPS_CHECK_HIP(hipGetDevice(&dev));
+  NDMPS_REQUIRE(dev >= 0 && dev < 64, "device index %d outside [0, 64)", dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!have[dev]) {
+    NDMPS_CHECK_HIP(hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming));
+    have[dev] = true;
+  } else {
+    NDMPS_CHECK_HIP(hipStreamWaitEvent(s, ev[dev], 0));
+  }
+  launch();
+  NDMPS_CHECK_HIP(hipEventRecord(ev[dev], s));
   return NDMPS_OK;
 }
 
@@ -1441,7 +1755,7 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
       chunk.v[t].status = 0;
       chunk.v[t].pad = 0;
     }
-    hipLaunchKernelGGL(trd_setdesc_kernel, dim3(1), dim3(kDescChunk), 0, s, desc, chunk, base, count);
+    hipLaunchKernelGGL(trd_setdesc_kernel, dim3(1), dim3(kDescChunk), 0, s, desc, chunk, base, count, w.sync);
   }
   const unsigned B = (unsigned)batch;
   const int load_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * l.lda, 256), 512);
@@ -1461,15 +1775,28 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
              : n_max <= 1024 ? trd_column_kernel<4, 32>
              : n_max <= 2048 ? trd_column_kernel<8, 32>
                              : trd_column_kernel<16, 32>;
+  // orders <= 512: one resident launch for all columns (trd_team_kernel; 2.2 ms for 1 .. 16 matrices of order
+  // 512, 2.5 ms for 32, against 2.4 / 3.8 / 5.7 ms of column launches); NDMPS_TRD_NO_TEAM=1 keeps the column
+  // launches (A/B timing, tests of that path)
+  const bool team = n_max <= 512 && n_max > kTail && !getenv("NDMPS_TRD_NO_TEAM");
   void* span = ndmps::span_begin(s);
   int64_t span_bytes = 0;  // algorithmic: every trailing element read once and written once per column
-  for (int j = 0; j < n_max - kTail; ++j) {
-    hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
-    if (span)
-      for (int b = 0; b < batch; ++b)
-        if (j < h_n[b] - kTail) span_bytes += 2 * 8 * (h_n[b] - j - 1) * (h_n[b] - j - 1);
+  if (team) {
+    NDMPS_TRY(team_launch(s, [&]() {
+      hipLaunchKernelGGL(trd_team_kernel<2>, dim3((unsigned)ndmps::ceil_div(n_max, 32), B), dim3(256), 0, s, desc, w);
+    }));
+    // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
+    for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
+    ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, span_bytes);
+  } else {
+    for (int j = 0; j < n_max - kTail; ++j) {
+      hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
+      if (span)
+        for (int b = 0; b < batch; ++b)
+          if (j < h_n[b] - kTail) span_bytes += 2 * 8 * (h_n[b] - j - 1) * (h_n[b] - j - 1);
+    }
+    ndmps::span_end(span, s, ndmps::kSpanTridiagColumns, std::max<int64_t>(n_max - kTail, 0), span_bytes);
   }
-  ndmps::span_end(span, s, ndmps::kSpanTridiagColumns, std::max<int64_t>(n_max - kTail, 0), span_bytes);
   hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
   const int kk = (int)std::min(k_max, n_max);
   hipLaunchKernelGGL(trd_bisect_kernel, dim3(ndmps::ceil_div(kk, 4), B), dim3(256),

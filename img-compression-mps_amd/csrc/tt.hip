@@ -1081,6 +1081,23 @@ extern "C" int ndmps_chain_contract_scatter_f32(int L, const int64_t* h_dims, co
   return chain_impl<float>(L, h_dims, h_bonds, h_cores, d_out, d_ws, ws_bytes, stream, &sc);
 }
 
+// The same for a list of MPS over the same sites (conv_to_tensors, evaluation/benchmark.py:80-100): volume b has
+// bonds h_bonds[b (L + 1) ..], cores h_cores[b L ..] and goes to h_out[b]; one workspace (sized for the largest
+// bonds) serves them in turn on `stream`.  The launches of all volumes are issued by this one call.
+extern "C" int ndmps_chain_contract_scatter_batched_f32(int batch, int L, const int64_t* h_dims, const int64_t* h_bonds,
+                                                        const float* const* h_cores, float* const* h_out,
+                                                        const int64_t* d_row_off, const int64_t* d_col_off,
+                                                        const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
+                                                        int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(batch >= 1 && L >= 1 && h_bonds && h_cores && h_out, "bad batched chain argument");
+  NDMPS_REQUIRE(d_row_off && d_col_off && d_col_perm && n_cols >= 1, "NULL scatter table");
+  ChainScatter sc{d_row_off, d_col_off, d_col_perm, n_cols};
+  for (int b = 0; b < batch; ++b)
+    NDMPS_TRY(chain_impl<float>(L, h_dims, h_bonds + (int64_t)b * (L + 1), h_cores + (int64_t)b * L, h_out[b], d_ws,
+                                ws_bytes, stream, &sc));
+  return NDMPS_OK;
+}
+
 extern "C" int ndmps_chain_contract_bf16(int L, const int64_t* h_dims, const int64_t* h_bonds,
                                          const void* const* h_cores, void* d_dense, void* d_ws,
                                          int64_t ws_bytes, ndmps_stream_t stream) {

@@ -58,7 +58,10 @@ def minmax_many(tensors, with_sumsq=False):
     import torch
 
     lib = _lib.load()
-    ts = [_f32(t) if _f32(t).is_contiguous() else _f32(t).contiguous() for t in tensors]
+    ts = []
+    for t in tensors:
+        u = _f32(t)
+        ts.append(u if u.is_contiguous() else u.contiguous())
     count = len(ts)
     if count == 0:
         return ([], []) if with_sumsq else []

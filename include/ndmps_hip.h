@@ -307,6 +307,14 @@ int ndmps_chain_contract_scatter_f32(int L, const int64_t* h_dims, const int64_t
                                      const int64_t* d_row_off, const int64_t* d_col_off,
                                      const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
                                      int64_t ws_bytes, ndmps_stream_t stream);
+/* The same for a list of MPS over the same sites (the reference reconstructs a list with a Python loop,
+ * evaluation/benchmark.py:80-100): volume b has bonds h_bonds[b (L + 1) ..], cores h_cores[b L ..] and is written
+ * to h_out[b]; d_ws (>= ndmps_chain_workspace_bytes of the largest bonds) serves the volumes in turn. */
+int ndmps_chain_contract_scatter_batched_f32(int batch, int L, const int64_t* h_dims, const int64_t* h_bonds,
+                                             const float* const* h_cores, float* const* h_out,
+                                             const int64_t* d_row_off, const int64_t* d_col_off,
+                                             const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
+                                             int64_t ws_bytes, ndmps_stream_t stream);
 /* C = A B with table-driven addressing of A and / or C: element (m, k) of A at d_A[d_a_row[m] + d_a_col[k]],
  * element (m, n) of C at d_C[d_c_row[m] + d_c_col[n]] (NULL pair: dense row-major).  a_vec4: d_a_col comes in
  * aligned runs of four consecutive offsets. */

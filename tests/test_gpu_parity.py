@@ -792,6 +792,28 @@ def test_fused_decode_is_bit_identical_to_chain_plus_permute(shape, chi):
     assert (n_tail > 0) == (len(obj.mps.dims) >= 2 and obj.mps.dims[-1] <= 4096)
 
 
+@pytest.mark.parametrize("shape,chi,mode,count", [((64, 64, 64), 16, "Std", 5), ((32, 32, 16, 24), 12, "DCT", 3),
+                                                  ((48, 40, 36), None, "Std", 2), ((7, 11, 13), 4, "Std", 3)], ids=str)
+def test_to_tensors_equals_to_tensor_per_object(shape, chi, mode, count):
+    """NDMPS.to_tensors issues the chain products of a whole list from one library call; same kernels on the same
+    operands as to_tensor per object, so bit-identical -- also for objects with different bonds (one of them is
+    truncated further) and through the NumPy return path."""
+    vols = [synthetic_mri(shape, seed=40 + i) if min(shape) > 8 else
+            np.random.default_rng(40 + i).random(shape).astype(np.float32) for i in range(count)]
+    objs = NDMPS.from_tensors(vols, mode=mode, max_bond=chi)
+    objs[-1].compress(0.05)
+    assert objs[-1].bond_sizes() != objs[0].bond_sizes() or chi is None or not objs[0].bond_sizes()  # (7, 11, 13): one site
+    one_by_one = [o.to_tensor(as_torch=True) for o in objs]
+    together = NDMPS.to_tensors(objs, as_torch=True)
+    assert len(together) == count
+    for a, b in zip(one_by_one, together):
+        assert a.shape == tuple(shape) and torch.equal(a, b)
+    as_numpy = NDMPS.to_tensors(objs)
+    assert all(isinstance(r, np.ndarray) and np.array_equal(r, a.cpu().numpy()) for r, a in zip(as_numpy, one_by_one))
+    assert NDMPS.to_tensors([]) == []
+    assert torch.equal(NDMPS.to_tensors(objs[:1], as_torch=True)[0], one_by_one[0])
+
+
 @pytest.mark.parametrize("shape,chi,mode", [((64, 64, 64), 16, "Std"), ((128, 128, 128), 64, "Std"),
                                             ((128, 128, 128), 32, "DCT"), ((64, 64, 64), 32, "DCT")], ids=str)
 def test_fused_encode_matches_permute_then_sweep(shape, chi, mode):
