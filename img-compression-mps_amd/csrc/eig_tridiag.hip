@@ -366,13 +366,13 @@ __device__ __forceinline__ void team_store(double* p, double v) {
 }
 
 template <int NR>
-__global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w) {
+__global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0) {
   constexpr int CW = 32;             // columns per workgroup
   constexpr int LPR = 8;             // lanes per row, 4 columns (32 bytes) each
   constexpr int RPW = 64 / LPR;      // rows per wave instruction
   constexpr int RPI = 4 * RPW;       // rows per tile of the workgroup
   constexpr int NT = 512 / RPI;      // tiles per lane: 512 rows
-  TrdDesc& d = desc[blockIdx.y];
+  TrdDesc& d = desc[b0 + blockIdx.y];
   const int n = d.n;
   const int J = n - kTail;           // columns 0 .. J - 1 are reduced here, the rest by the tail kernel
   const int c0 = blockIdx.x * CW;
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ 
   const int j_last = min(J - 1, c0 + CW - 2);  // the block's columns are finished once j + 1 >= c0 + CW
   const int lda = w.lda;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t b = blockIdx.y;
+  const int64_t b = b0 + blockIdx.y;
   double* A = w.A + b * w.n_max * lda;
   double* Vh = w.Vh + b * w.n_max * lda;
   double* ybuf = w.y + b * 2 * lda;
@@ -560,10 +560,11 @@ __global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ 
     }
     // ---- meeting of the matrix's workgroups (a block on its last column only announces itself)
     target += (unsigned long long)(nblk - (j + 1) / CW);
-    // exchange data are write-through atomic stores: once acknowledged (workgroup-scope release = wait for the
-    // memory counters) they are visible to the agent-scope loads of the other workgroups; no L2 write-back /
-    // invalidate, which would also flush what concurrent kernels of other streams keep there
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // exchange data are write-through agent-scope stores: once every storing wave has seen them acknowledged
+    // (vmcnt(0); a workgroup-scope release fence does not wait for the vector memory counter on this target) they
+    // are visible to the agent-scope loads of the other workgroups; no L2 write-back / invalidate, which would
+    // also flush what concurrent kernels of other streams keep there (an agent-scope release cost ~3x the time)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
       __hip_atomic_fetch_add(&sync->count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -588,7 +589,6 @@ __global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ 
     }
     __syncthreads();
     if (!go) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 
   // ---- hand-over to the tail kernel: the trailing block as the column launches would have left it (updates
@@ -1673,6 +1673,25 @@ int trd_opt_in() {
   return NDMPS_OK;
 }
 
+// workgroups of trd_team_kernel the current device keeps resident at once (occupancy x compute units)
+int team_slots(int& slots) {
+  static std::mutex mu;
+  static int cached[64] = {};
+  int dev = 0;
+  NDMPS_CHECK_HIP(hipGetDevice(&dev));
+  NDMPS_REQUIRE(dev >= 0 && dev < 64, "device index %d outside [0, 64)", dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (cached[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<2>, 256, 0));
+    NDMPS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // the register budget allows two 256-thread workgroups per CU; never count on more than that
+    cached[dev] = std::max(1, std::min(per_cu, 2)) * std::max(cus, 1);
+  }
+  slots = cached[dev];
+  return NDMPS_OK;
+}
+
 // At most one team kernel in flight per device (see trd_team_kernel): the launch waits for the previous one's
 // event on whatever stream it ran.
 template <typename F>
@@ -1782,8 +1801,16 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
   void* span = ndmps::span_begin(s);
   int64_t span_bytes = 0;  // algorithmic: every trailing element read once and written once per column
   if (team) {
+    // a launch never holds more workgroups than the device keeps resident at once: no team then depends on the
+    // order in which the dispatcher places workgroups (larger batches go in several launches)
+    const int team_size = (int)ndmps::ceil_div(n_max, 32);
+    int slots = 0;
+    NDMPS_TRY(team_slots(slots));
+    const int per_launch = std::max(1, slots / team_size);
     NDMPS_TRY(team_launch(s, [&]() {
-      hipLaunchKernelGGL(trd_team_kernel<2>, dim3((unsigned)ndmps::ceil_div(n_max, 32), B), dim3(256), 0, s, desc, w);
+      for (int b0 = 0; b0 < batch; b0 += per_launch)
+        hipLaunchKernelGGL(trd_team_kernel<2>, dim3((unsigned)team_size, (unsigned)std::min(per_launch, batch - b0)),
+                           dim3(256), 0, s, desc, w, b0);
     }));
     // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
     for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
