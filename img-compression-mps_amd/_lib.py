@@ -52,6 +52,10 @@ SIGNATURES = {
     "ndmps_gram_f32": (C.c_int, [vp, i64, i64, i64, vp, vp, i64, vp]),
     "ndmps_gemm_bf16_workspace_bytes": (i64, [C.c_int, i64, i64]),
     "ndmps_gemm_bf16": (C.c_int, [C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp]),
+    "ndmps_gram_batched_workspace_bytes": (i64, [C.c_int, i64, i64]),
+    "ndmps_gram_batched_f32": (C.c_int, [C.c_int, C.POINTER(vp), i64, i64, i64, vp, i64, vp, i64, vp]),
+    "ndmps_gram_batched_bf16": (C.c_int, [C.c_int, C.POINTER(vp), i64, i64, i64, vp, i64, vp, i64, vp]),
+    "ndmps_gram_batched_indexed_f32": (C.c_int, [C.c_int, C.POINTER(vp), i64, i64, vp, vp, vp, i64, vp, i64, vp]),
     "ndmps_gram_bf16": (C.c_int, [vp, i64, i64, i64, vp, vp, i64, vp]),
     "ndmps_convert_bf16_to_f32": (C.c_int, [vp, i64, vp, vp]),
     "ndmps_convert_f32_to_bf16": (C.c_int, [vp, i64, vp, vp]),

@@ -64,6 +64,7 @@ constexpr int kNumCU = 256;  // MI355X
 // launch spans for bench.py's roofline (util.hip); slot ids
 constexpr int kSpanTridiagColumns = 1;
 constexpr int kSpanTridiagTeam = 2;
+constexpr int kSpanGram = 3;  // `bytes` of the span = flops
 void* span_begin(hipStream_t s);
 void span_end(void* begin, hipStream_t s, int slot, int64_t launches, int64_t bytes);
 

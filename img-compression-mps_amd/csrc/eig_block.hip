@@ -307,7 +307,7 @@ __device__ __forceinline__ int64_t pair_index(int e, int lo, int hi) {  // e in 
 //   first    : diag role reads the initial matrix directly (nothing to apply yet)
 //   solve    : single block pair = whole matrix, iterate to convergence in LDS
 //   in, out  : G ping-pong indices;  q_cur: parity of the Q / D buffers being applied
-__global__ void __launch_bounds__(BS * BS)
+__global__ void __launch_bounds__(BS * BS, 2)
 blk_step_kernel(BatchDesc* __restrict__ desc, Work w, int n_diag, int t, int t_next, int full_next,
                 int sweep_next, int first, int solve, int in, int q_cur, int kTilesPerWg, int gstep) {
   constexpr int PS = 2 * BS, LD = PS + 1, NT = BS * BS;  // pair size, padded LDS row, threads
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(256) blk_rank_kernel(const BatchDesc* __restri
 // grid (ceil(k_max / 16), batch); NW waves per workgroup (8 while the LDS allows: two waves per SIMD hide
 // each other's LDS / history latency); dynamic LDS: np*17 + NW*32*33 doubles.
 template <int NW>
-__global__ void __launch_bounds__(64 * NW)
+__global__ void __launch_bounds__(64 * NW, 2)
 blk_backacc_kernel(const BatchDesc* __restrict__ desc, Work w, const int* __restrict__ kcols) {
   constexpr int NT = 64 * NW;
   constexpr int BS = 16, PS = 32, LDJ = PS + 1, LDY = 17;

@@ -16,6 +16,9 @@
 // read is 32 (16) consecutive words per half (quarter) wave: conflict-free ds_read.
 #include <algorithm>
 
+#include <mutex>
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -84,7 +87,7 @@ struct GemmIndex {
 };
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool VEC, bool IDX = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
             const T* __restrict__ B, int64_t ldb, T* __restrict__ C, int64_t ldc, GemmIndex ix = GemmIndex()) {
   using MF = Mfma<T>;
@@ -331,7 +334,7 @@ int gemm_check(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, int tra
 // goes to a partial buffer, reduced in fixed order (deterministic) by gram_reduce_kernel.
 // ----------------------------------------------------------------------------------
 template <int T, typename TIN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 gram_partial_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
                     double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab) {
   constexpr int TS = 16 * T;  // tile edge
@@ -480,7 +483,7 @@ __device__ __forceinline__ float4 load4_as_f32(const __bf16* p) {
 // the matrix is the C-order volume read through the index permutation (see GemmIndex); with vec_ok every aligned
 // group of four columns has consecutive offsets.
 template <int GW_TS, typename TIN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
                  double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab, int vec_ok,
                  const int64_t* __restrict__ row_off = nullptr, const int64_t* __restrict__ col_off = nullptr) {
@@ -592,6 +595,245 @@ gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
         const int rr = wr * SUB + 16 * a + lr + 4 * reg, cc = wc * SUB + 16 * b + lc;
         out[rr * GW_TS + cc] = acc[a][b][reg];
       }
+}
+
+// ----------------------------------------------------------------------------------
+// Gram for n >= 128, the dominant kernel of the bond-capped sweep (fp64 MFMA bound: 2 m n (n + 1) / 2 flops).
+// Same tiling as gram_wide_kernel<128> (128 x 128 tiles of the upper triangle x row slabs, 32-row chunks of
+// the two column panels in LDS, four waves of 64 x 64), rebuilt around what kept that kernel at 67 % of the
+// 78 TFLOP/s this GPU sustains on v_mfma_f64_16x16x4_f64 (tools/scratch/mfma_f64_rate.hip):
+//   * the chunks are double-buffered in LDS: the global loads of chunk c + 1 fly under the MFMAs of chunk c
+//     and are written to the other buffer afterwards -- ONE barrier per chunk, not two around a stall;
+//   * the operands of k-step s + 1 are read from LDS and converted before the MFMAs of step s are issued;
+//   * a DIAGONAL tile computes only the 16 x 16 tiles of its upper triangle (36 of 64): wave 0 / wave 3 the
+//     ten of a diagonal 64 x 64 block, waves 1 and 2 half of the off-diagonal block each -- 10 MFMAs per step
+//     on the critical wave instead of 16; diagonal tiles get 1.6 x longer slabs so all workgroups last alike;
+//   * one launch serves a whole batch of matrices (blockIdx.y): the small Grams of later sites fill the GPU
+//     and the slabs can be long (fewer partial tiles to write and reduce).
+// Partial tile of workgroup id of matrix b: partial[(b slots + id) 128^2 ..], off-diagonal tiles first
+// (tile-major, S_off slabs each), then the diagonal ones (S_diag slabs each); gram128_reduce_kernel sums a
+// tile's slabs in order (deterministic) and writes it mirrored.
+// ----------------------------------------------------------------------------------
+constexpr int G128_LD = 128 + 16;                 // padded LDS row (floats): fragment reads are conflict-free
+constexpr int G128_PANEL = GW_KB * G128_LD;       // floats per panel and buffer
+constexpr size_t kGram128Lds = (size_t)4 * G128_PANEL * sizeof(float);  // 2 buffers x 2 panels = 73.7 KB
+constexpr int kGram128MaxBatch = 48;              // matrices per launch (pointers travel as kernel arguments)
+
+struct Gram128Geom {
+  int tiles_1d, n_off, n_diag;
+  int slabs_off, slabs_diag;
+  int64_t rows_off, rows_diag;
+  int slots;  // workgroups = partial tiles per matrix
+};
+struct Gram128Ptrs {
+  const void* a[kGram128MaxBatch];
+};
+
+template <int ROLE>  // 0: 4 x 4 tiles; 1: upper triangle of a diagonal block (10 tiles); 2: 2 x 4 tiles
+__device__ __forceinline__ void gram128_load(const float* pa, const float* pb, int s, double (&av)[4], double (&bv)[4]) {
+  const int off = 4 * s * G128_LD;
+  if (ROLE == 1) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) av[a] = bv[a] = (double)pa[off + 16 * a];
+  } else {
+#pragma unroll
+    for (int a = 0; a < (ROLE == 2 ? 2 : 4); ++a) av[a] = (double)pa[off + 16 * a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bv[b] = (double)pb[off + 16 * b];
+  }
+}
+template <int ROLE>
+__device__ __forceinline__ void gram128_mfma(const double (&av)[4], const double (&bv)[4], f64x4 (&acc)[16]) {
+#pragma unroll
+  for (int a = 0; a < (ROLE == 2 ? 2 : 4); ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (ROLE != 1 || a <= b) acc[4 * a + b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[4 * a + b], 0, 0, 0);
+}
+// the eight k-steps of one chunk; pa / pb: this lane's element of row 0 of the two panels (LDS)
+template <int ROLE>
+__device__ __forceinline__ void gram128_chunk(const float* pa, const float* pb, f64x4 (&acc)[16]) {
+  double av[2][4], bv[2][4];
+  gram128_load<ROLE>(pa, pb, 0, av[0], bv[0]);
+#pragma unroll
+  for (int s = 0; s < GW_KB / 4; ++s) {
+    if (s + 1 < GW_KB / 4) gram128_load<ROLE>(pa, pb, s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+    gram128_mfma<ROLE>(av[s & 1], bv[s & 1], acc);
+  }
+}
+
+template <typename TIN>
+__global__ void __launch_bounds__(256, 2)
+gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __restrict__ partial, Gram128Geom g,
+               int vec_ok, const int64_t* __restrict__ row_off, const int64_t* __restrict__ col_off) {
+  extern __shared__ __attribute__((aligned(16))) float g128_lds[];  // [2 buffers][2 panels][GW_KB][G128_LD]
+  const TIN* __restrict__ A = static_cast<const TIN*>(ptrs.a[blockIdx.y]);
+  const int id = blockIdx.x;
+  int ti, tj, slab;
+  int64_t rows;
+  if (id < g.n_off * g.slabs_off) {
+    int t = id / g.slabs_off;
+    slab = id % g.slabs_off;
+    rows = g.rows_off;
+    ti = 0;
+    while (t >= g.tiles_1d - 1 - ti) {
+      t -= g.tiles_1d - 1 - ti;
+      ++ti;
+    }
+    tj = ti + 1 + t;
+  } else {
+    const int t = (id - g.n_off * g.slabs_off) / g.slabs_diag;
+    slab = (id - g.n_off * g.slabs_off) % g.slabs_diag;
+    rows = g.rows_diag;
+    ti = tj = t;
+  }
+  const bool diag = ti == tj;
+  const int64_t i0 = (int64_t)ti * 128, j0 = (int64_t)tj * 128;
+  const int64_t r_begin = (int64_t)slab * rows;
+  const int64_t r_end = min(m, r_begin + rows);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane >> 4, lc = lane & 15;
+
+  // staging map: GW_KB rows x 32 float4 per panel, 4 per thread
+  float4 pi[4], pj[4];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int e = tid + 256 * v;
+      const int rr = e / 32, c4 = (e % 32) * 4;
+      const int64_t row = r0 + rr;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+      if (row < r_end && row_off) {  // gathered: offsets additive in (row, column); vec_ok guaranteed by the host
+        const TIN* base = A + row_off[row];
+        if (i0 + c4 + 3 < n) x = load4_as_f32(base + col_off[i0 + c4]);
+        if (!diag && j0 + c4 + 3 < n) y = load4_as_f32(base + col_off[j0 + c4]);
+      } else if (row < r_end) {
+        const TIN* base = A + row * lda;
+        if (vec_ok && i0 + c4 + 3 < n) x = load4_as_f32(base + i0 + c4);
+        else {
+          if (i0 + c4 + 0 < n) x.x = (float)base[i0 + c4 + 0];
+          if (i0 + c4 + 1 < n) x.y = (float)base[i0 + c4 + 1];
+          if (i0 + c4 + 2 < n) x.z = (float)base[i0 + c4 + 2];
+          if (i0 + c4 + 3 < n) x.w = (float)base[i0 + c4 + 3];
+        }
+        if (!diag) {
+          if (vec_ok && j0 + c4 + 3 < n) y = load4_as_f32(base + j0 + c4);
+          else {
+            if (j0 + c4 + 0 < n) y.x = (float)base[j0 + c4 + 0];
+            if (j0 + c4 + 1 < n) y.y = (float)base[j0 + c4 + 1];
+            if (j0 + c4 + 2 < n) y.z = (float)base[j0 + c4 + 2];
+            if (j0 + c4 + 3 < n) y.w = (float)base[j0 + c4 + 3];
+          }
+        }
+      }
+      pi[v] = x;
+      pj[v] = y;
+    }
+  };
+  auto stash = [&](int buf) {
+    float* Pi = g128_lds + (2 * buf) * G128_PANEL;
+    float* Pj = Pi + G128_PANEL;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int e = tid + 256 * v;
+      const int rr = e / 32, c4 = (e % 32) * 4;
+      *reinterpret_cast<float4*>(Pi + rr * G128_LD + c4) = pi[v];
+      if (!diag) *reinterpret_cast<float4*>(Pj + rr * G128_LD + c4) = pj[v];
+    }
+  };
+
+  // operand columns of this wave inside the two panels
+  //   off-diagonal tile : wave (wr, wc) -> rows wr 64 of panel i, columns wc 64 of panel j
+  //   diagonal tile     : wave 0 -> block (0, 0), wave 3 -> block (1, 1) (upper triangles), waves 1 / 2 -> rows
+  //                       0..31 / 32..63 of block (0, 1); both operands from panel i
+  int a_col, b_col;
+  if (!diag) {
+    a_col = (wave >> 1) * 64;
+    b_col = (wave & 1) * 64;
+  } else if (wave == 0 || wave == 3) {
+    a_col = b_col = wave == 0 ? 0 : 64;
+  } else {
+    a_col = wave == 1 ? 0 : 32;
+    b_col = 64;
+  }
+
+  double* out = partial + ((int64_t)blockIdx.y * g.slots + id) * (128 * 128);
+  // one copy of the chunk loop per role (the role is fixed for the life of the wave; a branch per chunk made
+  // the register allocator keep the accumulators three times)
+  auto run = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;
+    f64x4 acc[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) acc[a] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    if (r_begin < r_end) {
+      fetch(r_begin);
+      stash(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += GW_KB, buf ^= 1) {
+      const bool more = r0 + GW_KB < r_end;
+      if (more) fetch(r0 + GW_KB);  // in flight under the MFMAs
+      const float* Pi = g128_lds + (2 * buf) * G128_PANEL + lr * G128_LD + lc;
+      const float* Pj = ROLE == 0 ? Pi + G128_PANEL : Pi;
+      gram128_chunk<ROLE>(Pi + a_col, Pj + b_col, acc);
+      if (more) stash(buf ^ 1);
+      __syncthreads();  // the other buffer is complete and nobody reads this one any more
+    }
+#pragma unroll
+    for (int a = 0; a < (ROLE == 2 ? 2 : 4); ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (ROLE == 1 && a > b) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int rr = a_col + 16 * a + lr + 4 * reg, cc = b_col + 16 * b + lc;
+          out[rr * 128 + cc] = acc[4 * a + b][reg];
+        }
+      }
+  };
+  if (!diag) run(std::integral_constant<int, 0>{});
+  else if (wave == 0 || wave == 3) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 2>{});
+}
+
+// G of matrix blockIdx.z from its partial tiles: tile t = blockIdx.x (off-diagonal ones first), element
+// e = blockIdx.y 256 + threadIdx.x; slabs summed in order, four in flight.
+__global__ void __launch_bounds__(256)
+gram128_reduce_kernel(const double* __restrict__ partial, Gram128Geom g, double* __restrict__ G, int64_t stride_G, int64_t n) {
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  const int t = blockIdx.x;
+  int ti, tj, base, count;
+  if (t < g.n_off) {
+    int u = t;
+    ti = 0;
+    while (u >= g.tiles_1d - 1 - ti) {
+      u -= g.tiles_1d - 1 - ti;
+      ++ti;
+    }
+    tj = ti + 1 + u;
+    base = t * g.slabs_off;
+    count = g.slabs_off;
+  } else {
+    ti = tj = t - g.n_off;
+    base = g.n_off * g.slabs_off + (t - g.n_off) * g.slabs_diag;
+    count = g.slabs_diag;
+  }
+  const int64_t r = (int64_t)ti * 128 + e / 128, c = (int64_t)tj * 128 + e % 128;
+  if (r >= n || c >= n || (ti == tj && c < r)) return;  // diagonal tiles: upper part only (the rest was not computed)
+  const double* src = partial + ((int64_t)blockIdx.z * g.slots + base) * (128 * 128) + e;
+  double s = 0.0;
+  int sl = 0;
+  for (; sl + 4 <= count; sl += 4) {
+    const double v0 = src[(int64_t)(sl + 0) * 16384], v1 = src[(int64_t)(sl + 1) * 16384];
+    const double v2 = src[(int64_t)(sl + 2) * 16384], v3 = src[(int64_t)(sl + 3) * 16384];
+    s = (((s + v0) + v1) + v2) + v3;
+  }
+  for (; sl < count; ++sl) s += src[(int64_t)sl * 16384];
+  double* Gb = G + (int64_t)blockIdx.z * stride_G;
+  Gb[r * n + c] = s;
+  Gb[c * n + r] = s;
 }
 
 // ----------------------------------------------------------------------------------
@@ -769,9 +1011,89 @@ GramGeom gram_wide_geometry(int64_t m, int64_t n) {
 inline bool gram_use_wide(int64_t m, int64_t n) { return n >= 64 && m >= 256; }
 inline bool gram_use_small(int64_t n) { return n <= 8; }
 
+// the 128-tile kernel: n >= 128 and at least 8 chunks of rows
+inline bool gram_use_128(int64_t m, int64_t n) { return n >= 128 && m >= 256; }
+
+// Slabs of gram128_kernel.  An off-diagonal workgroup costs 16 MFMAs per k-step, a diagonal one 10, so the
+// diagonal tiles get 1.6 x longer slabs.  One matrix alone fills the GPU once (~2 workgroups per CU); a batch is
+// cut into ~12 rounds of 512 workgroups (the tail of the last round is what is lost), never below 512 rows per
+// workgroup (128 for a lone matrix).  The geometry depends on (m, n, batch) only: a given call sequence is reproducible bit for bit.
+Gram128Geom gram128_geometry(int64_t m, int64_t n, int batch) {
+  Gram128Geom g;
+  g.tiles_1d = (int)ndmps::ceil_div(n, 128);
+  g.n_off = g.tiles_1d * (g.tiles_1d - 1) / 2;
+  g.n_diag = g.tiles_1d;
+  const double weight = g.n_off + 0.625 * g.n_diag;  // workgroups per off-diagonal slab count
+  const double want = 2.0 * ndmps::kNumCU * (batch > 1 ? 12.0 : 1.0) / std::max(batch, 1) / weight;
+  const int64_t floor_rows = batch > 1 ? 512 : 128;  // a lone small matrix still spreads over the GPU
+  int64_t s_off = std::max<int64_t>(1, std::min<int64_t>((int64_t)(want + 0.5), std::max<int64_t>(m / floor_rows, 1)));
+  g.rows_off = ndmps::round_up(ndmps::ceil_div(m, s_off), GW_KB);
+  g.rows_diag = ndmps::round_up((g.rows_off * 8 + 4) / 5, GW_KB);
+  g.slabs_off = (int)ndmps::ceil_div(m, g.rows_off);
+  g.slabs_diag = (int)ndmps::ceil_div(m, g.rows_diag);
+  g.slots = g.n_off * g.slabs_off + g.n_diag * g.slabs_diag;
+  return g;
+}
+
+inline int64_t gram128_workspace(int64_t m, int64_t n, int batch) {
+  return (int64_t)batch * gram128_geometry(m, n, batch).slots * 128 * 128 * (int64_t)sizeof(double) + 256;
+}
+
+int gram128_opt_in() {
+  static std::mutex mu;
+  static bool done[64] = {};
+  int dev = 0;
+  NDMPS_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev < 0 || dev >= 64 || done[dev]) return NDMPS_OK;
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram128_kernel<float>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGram128Lds));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram128_kernel<__bf16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGram128Lds));
+  done[dev] = true;
+  return NDMPS_OK;
+}
+
+// G[b] = A[b]^T A[b] for `batch` matrices of one shape (h_A: host array of device pointers)
+template <typename TIN>
+int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int64_t lda, double* d_G, int64_t stride_G,
+                    void* d_ws, int64_t ws_bytes, hipStream_t s, const int64_t* d_row_off, const int64_t* d_col_off) {
+  NDMPS_REQUIRE(batch >= 1 && h_A && d_G && gram_use_128(m, n) && lda >= n && stride_G >= n * n,
+                "bad batched Gram argument (batch=%d m=%lld n=%lld)", batch, (long long)m, (long long)n);
+  const int64_t need = gram128_workspace(m, n, batch);
+  if (!d_ws || ws_bytes < need) {
+    ndmps::set_error("Gram workspace too small: %lld < %lld", (long long)ws_bytes, (long long)need);
+    return NDMPS_EWORKSPACE;
+  }
+  NDMPS_TRY(gram128_opt_in());
+  const Gram128Geom g = gram128_geometry(m, n, batch);
+  int vec_ok = (lda % 4 == 0 && n % 4 == 0) ? 1 : 0;
+  for (int b = 0; b < batch; ++b) {
+    NDMPS_REQUIRE(h_A[b], "NULL Gram operand %d", b);
+    if ((uintptr_t)h_A[b] % (4 * sizeof(TIN)) != 0) vec_ok = 0;
+  }
+  if (d_row_off)
+    NDMPS_REQUIRE(d_col_off && vec_ok, "gathered Gram needs n %% 4 == 0 and aligned bases");
+  double* partial = (double*)d_ws;
+  void* span = ndmps::span_begin(s);
+  for (int base = 0; base < batch; base += kGram128MaxBatch) {
+    const int count = std::min(kGram128MaxBatch, batch - base);
+    Gram128Ptrs ptrs;
+    for (int t = 0; t < count; ++t) ptrs.a[t] = h_A[base + t];
+    hipLaunchKernelGGL(gram128_kernel<TIN>, dim3(g.slots, count), dim3(256), kGram128Lds, s, ptrs, m, n, lda,
+                       partial + (int64_t)base * g.slots * 16384, g, vec_ok, d_row_off, d_col_off);
+  }
+  // algorithmic work of the span: the upper triangle incl. the diagonal, 2 flops per product
+  ndmps::span_end(span, s, ndmps::kSpanGram, (batch + kGram128MaxBatch - 1) / kGram128MaxBatch, (int64_t)batch * m * n * (n + 1));
+  hipLaunchKernelGGL(gram128_reduce_kernel, dim3(g.n_off + g.n_diag, 64, batch), dim3(256), 0, s, partial, g, d_G, stride_G, n);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
 extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
   if (m <= 0 || n <= 0) return 0;
   if (gram_use_small(n)) return (int64_t)kGramSmallBlocks * 36 * 8 + 256;
+  if (gram_use_128(m, n)) return gram128_workspace(m, n, 1);
   if (gram_use_wide(m, n)) {
     GramGeom g = gram_wide_geometry(m, n);
     const int64_t ts = gram_wide_tile(n);
@@ -810,15 +1132,10 @@ int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, voi
     NDMPS_LAUNCH_CHECK();
     return NDMPS_OK;
   }
+  if (gram_use_128(m, n)) return gram128_batched<TIN>(1, &d_A, m, n, lda, d_G, n * n, d_ws, ws_bytes, s, d_row_off, d_col_off);
   if (gram_use_wide(m, n)) {
     GramGeom gw = gram_wide_geometry(m, n);
     NDMPS_REQUIRE(gw.n_slabs < 65536, "Gram slab count %d exceeds grid.y", gw.n_slabs);
-    if (gram_wide_tile(n) == 128) {
-      hipLaunchKernelGGL((gram_wide_kernel<128, TIN>), dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
-                         partial, gw.tiles_1d, gw.rows_per_slab, vec_ok, d_row_off, d_col_off);
-      NDMPS_LAUNCH_CHECK();
-      return launch_tile_reduce<128>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
-    }
     hipLaunchKernelGGL((gram_wide_kernel<64, TIN>), dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
                        partial, gw.tiles_1d, gw.rows_per_slab, vec_ok, d_row_off, d_col_off);
     NDMPS_LAUNCH_CHECK();
@@ -854,6 +1171,31 @@ extern "C" int ndmps_gram_indexed_f32(const float* d_base, int64_t m, int64_t n,
                                       ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_row_off && d_col_off, "NULL offset table");
   return gram_any<float>(d_base, m, n, n, d_G, d_ws, ws_bytes, stream, d_row_off, d_col_off);
+}
+
+// Batched Gram of `batch` matrices of one shape (n >= 128, m >= 256): h_A[b] (host array of device pointers) ->
+// d_G + b stride_G.  One launch for the whole batch (what a lockstep group of volumes needs at a site).
+extern "C" int64_t ndmps_gram_batched_workspace_bytes(int batch, int64_t m, int64_t n) {
+  if (batch <= 0 || !gram_use_128(m, n)) return 0;
+  return gram128_workspace(m, n, batch);
+}
+extern "C" int ndmps_gram_batched_f32(int batch, const float* const* h_A, int64_t m, int64_t n, int64_t lda,
+                                      double* d_G, int64_t stride_G, void* d_ws, int64_t ws_bytes,
+                                      ndmps_stream_t stream) {
+  return gram128_batched<float>(batch, h_A, m, n, lda, d_G, stride_G, d_ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr);
+}
+extern "C" int ndmps_gram_batched_bf16(int batch, const void* const* h_A, int64_t m, int64_t n, int64_t lda,
+                                       double* d_G, int64_t stride_G, void* d_ws, int64_t ws_bytes,
+                                       ndmps_stream_t stream) {
+  return gram128_batched<__bf16>(batch, (const __bf16* const*)h_A, m, n, lda, d_G, stride_G, d_ws, ws_bytes,
+                                 (hipStream_t)stream, nullptr, nullptr);
+}
+extern "C" int ndmps_gram_batched_indexed_f32(int batch, const float* const* h_base, int64_t m, int64_t n,
+                                              const int64_t* d_row_off, const int64_t* d_col_off, double* d_G,
+                                              int64_t stride_G, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_row_off && d_col_off, "NULL offset table");
+  return gram128_batched<float>(batch, h_base, m, n, n, d_G, stride_G, d_ws, ws_bytes, (hipStream_t)stream, d_row_off,
+                                d_col_off);
 }
 
 // same with a bf16 matrix (products of two bf16 numbers are exact in fp32, let alone fp64)

@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16x8 load8(const bf16* __restrict__ base, int64_t l
   return v;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 gemm_bf16_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ Bt, int64_t ldb,
                  bf16* __restrict__ C, int64_t ldc, int64_t m, int64_t n, int64_t K, int vec_in, int vec_out) {
   __shared__ __attribute__((aligned(16))) bf16 smem[(BM + BN) * BK];  // 32 KB: A tile, B tile; then the C tile

@@ -197,8 +197,11 @@ __global__ void merge_basis_init_kernel(double* __restrict__ W, int64_t stride_w
 // Fused reshape stage: the raw Gram pass reads the volume with its columns in MEMORY order (perm[c'] = site-order
 // column of the c'-th smallest offset): G'[a][b] = G[perm[a]][perm[b]].  Back to site order:
 __global__ void __launch_bounds__(256)
-unpermute_gram_kernel(const double* __restrict__ Gp, int64_t n, const int32_t* __restrict__ perm, double* __restrict__ G) {
+unpermute_gram_kernel(const double* __restrict__ Gp, int64_t n, const int32_t* __restrict__ perm, double* __restrict__ G,
+                      int64_t stride) {  // matrix blockIdx.y at Gp / G + blockIdx.y * stride
   const int64_t total = n * n;
+  Gp += (int64_t)blockIdx.y * stride;
+  G += (int64_t)blockIdx.y * stride;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
     G[(int64_t)perm[e / n] * n + perm[e % n]] = Gp[e];
 }
@@ -262,7 +265,7 @@ inline int64_t eig_workspace_bytes(int64_t n_max, int batch, int64_t max_bond) {
 // upper bound of ndmps_gram_workspace_bytes(m, n') over every n' <= n (the actual bond may
 // come out smaller than the worst case the layout is sized for): slabs * tiles <=
 // max(1024, tiles(n)), 64 x 64 doubles each.
-int64_t gram_ws_bound(int64_t n) {
+int64_t gram_ws_bound(int64_t n, int batch = 1) {
   const int64_t t1 = ceil_div(n, 64);
   // (slabs + slabs/16 + 2) * tiles tiles of 64 x 64 doubles, slabs * tiles <= max(512, tiles(n))
   const int64_t nt1 = t1 * (t1 + 1) / 2;
@@ -271,7 +274,10 @@ int64_t gram_ws_bound(int64_t n) {
   const int64_t t2 = ceil_div(n, 128);
   const int64_t nt2 = t2 * (t2 + 1) / 2;
   const int64_t wide = (std::max<int64_t>(512, nt2) * 17 / 16 + 3 * nt2) * 16384 * 8 + 256;
-  return std::max(narrow, wide);
+  // a lockstep group in one launch (ndmps_gram_batched_*): ~12 rounds of 512 partial tiles in total, plus the
+  // rounding of the slab counts per matrix
+  const int64_t batched = batch > 1 ? (12 * 512 + 3 * nt2 * batch + 64) * 16384 * 8 + 256 : 0;
+  return std::max(std::max(narrow, wide), batched);
 }
 
 // ------------------------------------------------------------------ sweep layout (worst case)
@@ -316,7 +322,7 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
     if (i >= 1) {
       const int64_t small = std::min(m, n);
       out.small_max = std::max(out.small_max, small);
-      if (n <= m) out.gram_ws = std::max(out.gram_ws, gram_ws_bound(n));
+      if (n <= m) out.gram_ws = std::max(out.gram_ws, gram_ws_bound(n, batch));
       else out.wide_elems = std::max(out.wide_elems, m * n);
     }
   }
@@ -325,7 +331,7 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
   out.merge_w = out.merge_from < L ? std::min(out.merge_n, max_bond) : 0;
   if (out.merge_from < L) {
     out.small_max = std::max(out.small_max, out.merge_n);
-    out.gram_ws = std::max(out.gram_ws, gram_ws_bound(out.merge_n));
+    out.gram_ws = std::max(out.gram_ws, gram_ws_bound(out.merge_n, batch));
   }
   // Rank decision on the device: possible when every site's eigenproblem (order min(rows, d_i cap_{i+1}) with
   // the bonds at their caps) goes to the direct top-k solver.  The sweep then sizes everything by the caps,
@@ -393,6 +399,24 @@ inline int gram_T(const float* A, int64_t m, int64_t n, int64_t lda, double* G, 
 }
 inline int gram_T(const __bf16* A, int64_t m, int64_t n, int64_t lda, double* G, void* ws, int64_t wsb, hipStream_t s) {
   return ndmps_gram_bf16(A, m, n, lda, G, ws, wsb, s);
+}
+// one launch for the Gram matrices of a lockstep group (same shape; n >= 128, m >= 256)
+inline int gram_batched_T(int batch, const float* const* A, int64_t m, int64_t n, double* G, int64_t stride, void* ws,
+                          int64_t wsb, hipStream_t s) {
+  return ndmps_gram_batched_f32(batch, A, m, n, n, G, stride, ws, wsb, s);
+}
+inline int gram_batched_T(int batch, const __bf16* const* A, int64_t m, int64_t n, double* G, int64_t stride, void* ws,
+                          int64_t wsb, hipStream_t s) {
+  return ndmps_gram_batched_bf16(batch, (const void* const*)A, m, n, n, G, stride, ws, wsb, s);
+}
+inline int gram_batched_src(int batch, const float* const* vol, int64_t m, int64_t n, const SweepSource& src, double* G,
+                            int64_t stride, void* ws, int64_t wsb, hipStream_t s) {
+  return ndmps_gram_batched_indexed_f32(batch, vol, m, n, src.row_off, src.col_off, G, stride, ws, wsb, s);
+}
+inline int gram_batched_src(int, const __bf16* const*, int64_t, int64_t, const SweepSource&, double*, int64_t, void*,
+                            int64_t, hipStream_t) {
+  ndmps::set_error("the fused reshape stage is fp32 only");
+  return NDMPS_EINVAL;
 }
 // C (m, n) = A (m, k) op(B);  tws: scratch of the bf16 path (transposed copy of a (k, n) right operand)
 inline int gemm_T(int transB, int64_t m, int64_t n, int64_t k, const float* A, const float* B, int64_t ldb, float* C,
@@ -549,15 +573,28 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     const int i0 = lay.merge_from;
     const int64_t n0 = lay.merge_n, ldw = lay.merge_w, m0 = lay.numel / n0;
     const int64_t stride_top = n0 * n0, stride_w = n0 * ldw;
-    for (int b = 0; b < batch; ++b) {
+    const int64_t raw_batched = ndmps_gram_batched_workspace_bytes(batch, m0, n0);
+    if (batch > 1 && raw_batched > 0 && raw_batched <= lay.gram_ws) {
+      // the whole group in one launch (long slabs: a fraction of the partial tiles, no launch gaps)
       if (src) {
-        double* Gp = Tm + (int64_t)b * stride_top;  // columns in memory order; T is free until stage 1
-        NDMPS_TRY(gram_src(cur[b], m0, n0, *src, Gp, gram_ws, lay.gram_ws, s));
-        hipLaunchKernelGGL(unpermute_gram_kernel, dim3(grid1d(n0 * n0)), dim3(256), 0, s, Gp, n0, src->col_perm,
-                           Graw + (int64_t)b * stride_top);
+        NDMPS_TRY(gram_batched_src(batch, cur.data(), m0, n0, *src, Tm, stride_top, gram_ws, lay.gram_ws, s));
+        hipLaunchKernelGGL(unpermute_gram_kernel, dim3(grid1d(n0 * n0), batch), dim3(256), 0, s, Tm, n0, src->col_perm,
+                           Graw, stride_top);
         NDMPS_LAUNCH_CHECK();
       } else {
-        NDMPS_TRY(gram_T(cur[b], m0, n0, n0, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
+        NDMPS_TRY(gram_batched_T(batch, cur.data(), m0, n0, Graw, stride_top, gram_ws, lay.gram_ws, s));
+      }
+    } else {
+      for (int b = 0; b < batch; ++b) {
+        if (src) {
+          double* Gp = Tm + (int64_t)b * stride_top;  // columns in memory order; T is free until stage 1
+          NDMPS_TRY(gram_src(cur[b], m0, n0, *src, Gp, gram_ws, lay.gram_ws, s));
+          hipLaunchKernelGGL(unpermute_gram_kernel, dim3(grid1d(n0 * n0), 1), dim3(256), 0, s, Gp, n0, src->col_perm,
+                             Graw + (int64_t)b * stride_top, stride_top);
+          NDMPS_LAUNCH_CHECK();
+        } else {
+          NDMPS_TRY(gram_T(cur[b], m0, n0, n0, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
+        }
       }
     }
     hipLaunchKernelGGL(merge_basis_init_kernel, dim3(batch), dim3(1), 0, s, Wm[0], stride_w);
@@ -632,7 +669,20 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
   for (int i = i_start; i >= 1; --i) {
     // ---- small-side Gram matrices
     int64_t m = 0;
-    for (int b = 0; b < batch; ++b) {
+    // same shape in every volume (always so when the ranks are decided on the device): one Gram launch
+    bool together = batch > 1;
+    for (int b = 1; b < batch && together; ++b) together = chi_r[b] == chi_r[0] && cur_elems[b] == cur_elems[0];
+    if (together) {
+      const int64_t n = h_dims[i] * chi_r[0];
+      m = cur_elems[0] / n;
+      const int64_t need = n <= m ? ndmps_gram_batched_workspace_bytes(batch, m, n) : 0;
+      together = need > 0 && need <= lay.gram_ws && n * n <= sq;
+      if (together) {
+        for (int b = 0; b < batch; ++b) eig_n[b] = n;
+        NDMPS_TRY(gram_batched_T(batch, cur.data(), m, n, G, sq, gram_ws, lay.gram_ws, s));
+      }
+    }
+    for (int b = 0; b < batch && !together; ++b) {
       const int64_t n = h_dims[i] * chi_r[b];
       m = cur_elems[b] / n;
       eig_n[b] = std::min(m, n);

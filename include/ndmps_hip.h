@@ -140,6 +140,19 @@ int64_t ndmps_gemm_bf16_workspace_bytes(int transB, int64_t n, int64_t k);
 int ndmps_gemm_bf16(int transB, int64_t m, int64_t n, int64_t k, const void* d_A, int64_t lda,
                     const void* d_B, int64_t ldb, void* d_C, int64_t ldc, void* d_ws, int64_t ws_bytes,
                     ndmps_stream_t stream);
+/* The same for `batch` matrices of one shape in ONE launch (n >= 128, m >= 256; what a lockstep group of
+ * volumes needs at a site of the sweep, core/ndmps.py:74 per volume in the reference): h_A is a HOST array of
+ * device pointers, G of matrix b goes to d_G + b * stride_G.  _indexed: element (r, c) of matrix b is
+ * h_base[b][d_row_off[r] + d_col_off[c]] (see ndmps_gram_indexed_f32). */
+int64_t ndmps_gram_batched_workspace_bytes(int batch, int64_t m, int64_t n);
+int ndmps_gram_batched_f32(int batch, const float* const* h_A, int64_t m, int64_t n, int64_t lda, double* d_G,
+                           int64_t stride_G, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+int ndmps_gram_batched_bf16(int batch, const void* const* h_A, int64_t m, int64_t n, int64_t lda, double* d_G,
+                            int64_t stride_G, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+int ndmps_gram_batched_indexed_f32(int batch, const float* const* h_base, int64_t m, int64_t n,
+                                   const int64_t* d_row_off, const int64_t* d_col_off, double* d_G,
+                                   int64_t stride_G, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+
 /* G = A^T A for a bf16 matrix A (products exact, fp64 accumulation); workspace as ndmps_gram_f32 */
 int ndmps_gram_bf16(const void* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, void* d_ws,
                     int64_t ws_bytes, ndmps_stream_t stream);

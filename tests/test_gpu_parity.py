@@ -818,10 +818,9 @@ def test_to_tensors_equals_to_tensor_per_object(shape, chi, mode, count):
                                             ((128, 128, 128), 32, "DCT"), ((64, 64, 64), 32, "DCT")], ids=str)
 def test_fused_encode_matches_permute_then_sweep(shape, chi, mode):
     """The bond-capped fp32 sweep reads the volume through the permutation tables (raw Gram pass + projection of
-    the merged run); no site-order tensor is formed and the input is left untouched.  The Gram matrices -- hence
-    the cores of the merged sites -- are bit-identical to the unfused route (same sums in the same row order);
-    the carried matrix sums its products over the columns in memory order instead of site order, so everything
-    downstream agrees to fp32 rounding."""
+    the merged run); no site-order tensor is formed and the input is left untouched.  The Gram matrices agree with
+    the unfused route to fp64 rounding; the carried matrix sums its products over the columns in memory order
+    instead of site order, so everything downstream agrees to fp32 rounding."""
     lib = _lib.load()
     x = torch.from_numpy(synthetic_mri(shape, seed=13)).to(DEV)
     keep = x.clone()
@@ -862,10 +861,11 @@ def test_fused_encode_matches_permute_then_sweep(shape, chi, mode):
         k0, k1 = int(bonds[i]), int(bonds[i + 1])
         ref = arena[int(core_off[i]): int(core_off[i]) + k0 * dims[i] * k1].view(k0, dims[i], k1)
         ref_cores.append(ref)
-        if i >= merged_from:
-            assert torch.equal(core, ref), i  # Gram-derived: bit-identical
-    # cores further left are eigenvectors of Gram matrices of the carried matrix (differently rounded, and
-    # inside noise-floor clusters individually ill-conditioned): compare what they represent
+    assert merged_from >= 1
+    # the two routes sum the same exact products, but a pair of columns that shares a diagonal tile in memory order
+    # may sit in an off-diagonal one in site order, and those have different slab lengths (gram128_kernel): the
+    # Gram matrices agree to fp64 rounding, not bit for bit.  Cores are eigenvectors (inside noise-floor clusters
+    # individually ill-conditioned): compare what they represent
     a, b = fused.mps.to_dense(), DeviceMPS(ref_cores).to_dense()
     assert float((a - b).norm() / b.norm()) <= 2e-6
 
