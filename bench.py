@@ -8,7 +8,7 @@ applied in the sweep, then NDMPS.to_tensor) on synthetic 256^3 fp32 volumes at c
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One process per GPU; a step is one batch of --batch independent volumes per GPU (encoded in lockstep
-groups by NDMPS.from_tensors, reconstructed one by one); independent volumes shard over the ranks with
+groups by NDMPS.from_tensors, reconstructed by NDMPS.to_tensors); independent volumes shard over the ranks with
 no data-path collective -> weak scaling; the only collective before the timed region is the
 RCCL broadcast of the job descriptor.  Rank 0 prints one JSON line.  At N = 1 it also carries the CPU
 baseline (the NumPy oracle on one volume of the batch, timed on the host cores) and the SSIM gap between
@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+F64_MFMA_PEAK_TFLOPS = 78.6  # dense v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk per SIMD at 2.4 GHz (measured 77.7)
 METRIC = "Mvoxels/s compress+reconstruct, 256^3 fp32, bond chi=64; SSIM vs ref"
 FIRST_SEED = 2025  # the reference tests' seed; volume j of the job uses FIRST_SEED + j
 
@@ -221,74 +222,108 @@ def main():
     value = throughput(job, n_vox, args.steps, elapsed)
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- roofline of the dominant kernel (largest share of device time, profiles/r02_*): the column launches of
-    # the Householder tridiagonalisation.  Every launch reads and writes the trailing matrices once (fp64):
-    # algorithmic bytes = 2 * 8 * sum over its matrices of (n - j - 1)^2, counted by the library per launch;
-    # duration = HIP events on the launching stream around every column sweep of the TIMED REGION.
+    # ---- roofline of the dominant kernel (largest share of device time, profiles/r02_*): gram128_kernel, the fp64
+    # Gram matrices of a lockstep group in one launch.  MFMA-bound (v_mfma_f64_16x16x4_f64): algorithmic flops =
+    # m n (n + 1) per matrix (upper triangle incl. the diagonal, 2 flops per product), counted by the library
+    # per launch; duration = HIP events on the launching stream around every Gram launch of the TIMED REGION.
     import ctypes as C
 
-    ms, launches, nbytes = C.c_double(), C.c_int64(), C.c_int64()
-    _lib.check(lib.ndmps_profile_collect(1, C.byref(ms), C.byref(launches), C.byref(nbytes)))
-    col_us = max(ms.value * 1e3 / max(launches.value, 1), 1e-9)
-    col_bytes = nbytes.value / max(launches.value, 1)
-    achieved = col_bytes / (col_us * 1e-6) / 1e9 if launches.value else float("nan")
-    traffic, pmc_entry = pmc_traffic("trd_column_kernel")
+    def collect(slot):
+        ms, launches, amount = C.c_double(), C.c_int64(), C.c_int64()
+        _lib.check(lib.ndmps_profile_collect(slot, C.byref(ms), C.byref(launches), C.byref(amount)))
+        return ms.value, launches.value, amount.value
+
+    SLOT_TEAM, SLOT_GRAM = 2, 3
+    g_ms, g_launches, g_flops = collect(SLOT_GRAM)
+    t_ms, t_launches, t_bytes = collect(SLOT_TEAM)
+    gram_us = g_ms * 1e3 / max(g_launches, 1)
+    gram_flops = g_flops / max(g_launches, 1)
+    achieved = gram_flops / (gram_us * 1e-6) / 1e12 if g_launches else float("nan")
+    traffic, pmc_entry = pmc_traffic("gram128_kernel")
     algo_bytes_e2e = 2 * 4 * n_vox
     roofline = {
-        "kernel": "trd_column_kernel<2, 32> (Householder tridiagonalisation, one launch per column, 16 order-512 "
-                  "matrices per launch and group)",
-        "bound": "hbm",
+        "kernel": "gram128_kernel<float> (fp64 Gram matrices A^T A of a lockstep group in one launch, "
+                  "v_mfma_f64_16x16x4_f64; all sites' launches averaged, the 32768 x 512 raw Gram dominates)",
+        "bound": "mfma",
         "achieved": achieved,
-        "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBPS,
+        "peak": F64_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / F64_MFMA_PEAK_TFLOPS,
         "traffic": traffic,
-        "bytes_per_launch": col_bytes,
-        "launch_us": col_us,
-        "launches_per_step": launches.value / args.steps,
-        "measured": "HIP events on the launching streams around every column sweep of the timed region "
-                    f"({job['groups']} groups in flight share the HBM)",
+        "flops_per_launch": gram_flops,
+        "launch_us": gram_us,
+        "launches_per_step": g_launches / args.steps,
+        "measured": "HIP events on the launching streams around every Gram launch of the timed region "
+                    f"({job['groups']} groups in flight share the matrix cores)",
+        "peak_source": "AMD MI355X spec, FP64 matrix 78.6 TFLOP/s = 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz; "
+                       "77.7 measured with tools/scratch/mfma_f64_rate.hip (MI355X_MICROARCH.md lists no f64 row)",
         "traffic_source": pmc_entry,
         "end_to_end_algorithmic_GBps": job["batch_per_gpu"] * algo_bytes_e2e / (ms_per_step * 1e-3) / 1e9,
         "end_to_end_frac": job["batch_per_gpu"] * algo_bytes_e2e / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        # second kernel by device time: the register-resident Householder tridiagonalisation (latency-bound: one
+        # exchange between the workgroups of a matrix per column, no trailing-matrix traffic)
+        "tridiagonalisation": {
+            "kernel": "trd_team_kernel<2>",
+            "launch_ms": t_ms / max(t_launches, 1),
+            "launches_per_step": t_launches / args.steps,
+            "hbm_bytes_per_launch_algorithmic": t_bytes / max(t_launches, 1),
+            "bound": "latency of the per-column exchange (384 columns per order-512 matrix)",
+        },
     }
 
-    # the same launches with nothing else on the GPU: 16 Gram matrices of order 512 built from the batch (the
-    # shape of the three big eigenproblems of every volume), one stream
+    # the same Gram launch with nothing else on the GPU: one lockstep group's raw Gram (m = N / 512 rows, 512 columns)
     if not args.skip_single and job["size"] >= 64:
-        nb_eig, n_eig = 16, 512
-        a = torch.stack([xs[j % len(xs)].reshape(n_eig, -1).to(torch.float64) for j in range(nb_eig)])
-        g0 = torch.bmm(a, a.transpose(1, 2)).contiguous()
-        del a
-        vv = torch.empty_like(g0)
-        ww = torch.empty((nb_eig, n_eig), dtype=torch.float64, device=device)
-        wsb_n = lib.ndmps_syevd_topk_workspace_bytes(n_eig, nb_eig, job["chi"])
-        wsb = torch.empty(int(wsb_n), dtype=torch.uint8, device=device)
-        sizes = _lib.i64_array([n_eig] * nb_eig)
+        nb, n_g = min(32, len(xs)), 512
+        m_g = n_vox // n_g
+        nbytes_g = lib.ndmps_gram_batched_workspace_bytes(nb, m_g, n_g)
+        if nbytes_g > 0:
+            gws = torch.empty(int(nbytes_g), dtype=torch.uint8, device=device)
+            gout = torch.empty((nb, n_g, n_g), dtype=torch.float64, device=device)
+            ptrs = (C.c_void_p * nb)(*[xs[j].data_ptr() for j in range(nb)])
 
-        def values():
-            _lib.check(lib.ndmps_syevd_topk_values_f64(nb_eig, g0.data_ptr(), n_eig * n_eig, sizes, vv.data_ptr(),
-                                                       n_eig * n_eig, ww.data_ptr(), n_eig, min(job["chi"], 128),
-                                                       wsb.data_ptr(), wsb_n, _lib.stream_ptr()))
+            def gram_alone():
+                _lib.check(lib.ndmps_gram_batched_f32(nb, ptrs, m_g, n_g, n_g, gout.data_ptr(), n_g * n_g, gws.data_ptr(),
+                                                      nbytes_g, _lib.stream_ptr()))
 
-        values()
+            gram_alone()
+            torch.cuda.synchronize()
+            _lib.check(lib.ndmps_profile_enable(1))
+            for _ in range(3):
+                gram_alone()
+            torch.cuda.synchronize()
+            _lib.check(lib.ndmps_profile_enable(0))
+            i_ms, i_launches, i_flops = collect(SLOT_GRAM)
+            iso_us = max(i_ms * 1e3 / max(i_launches, 1), 1e-9)
+            iso_tf = i_flops / max(i_launches, 1) / (iso_us * 1e-6) / 1e12
+            roofline["isolated"] = {
+                "workload": f"{nb} x ({m_g} x {n_g}) fp32 matrices (the C-order volumes), one launch, nothing else on the GPU",
+                "launch_us": iso_us,
+                "achieved": iso_tf,
+                "frac": iso_tf / F64_MFMA_PEAK_TFLOPS,
+            }
+            del gws, gout
+        # reshape stage alone (the kernel north_star's ">= 50 % of the HBM-read roofline" refers to): the bond-capped
+        # fp32 path never runs it (the permutation rides on the Gram pass, the projection and the last chain
+        # product), other paths do: the tiled permute of one volume, HIP events around 10 launches
+        from imgcompressionmps_amd.core.ndmps import _plan_for
+
+        plan = _plan_for(shape, device.index or 0)
+        dense = torch.empty(n_vox, dtype=torch.float32, device=device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), 4, _lib.stream_ptr()))
+        e0.record()
+        for _ in range(10):
+            _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), 4, _lib.stream_ptr()))
+        e1.record()
         torch.cuda.synchronize()
-        _lib.check(lib.ndmps_profile_enable(1))
-        for _ in range(3):
-            values()
-        torch.cuda.synchronize()
-        _lib.check(lib.ndmps_profile_enable(0))
-        _lib.check(lib.ndmps_profile_collect(1, C.byref(ms), C.byref(launches), C.byref(nbytes)))
-        iso_us = max(ms.value * 1e3 / max(launches.value, 1), 1e-9)
-        iso_bytes = nbytes.value / max(launches.value, 1)
-        roofline["isolated"] = {
-            "workload": f"{nb_eig} x ({n_eig} x {n_eig}) fp64 Gram matrices, one stream, nothing else on the GPU",
-            "launch_us": iso_us,
-            "bytes_per_launch": iso_bytes,
-            "achieved": iso_bytes / (iso_us * 1e-6) / 1e9,
-            "frac": iso_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+        perm_ms = e0.elapsed_time(e1) / 10
+        roofline["reshape_stage"] = {
+            "kernel": "encode_tiled_kernel<uint32, vec>",
+            "launch_us": perm_ms * 1e3,
+            "read_frac": (4 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
+            "read_write_frac": (8 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
         }
-        del g0, vv, ww, wsb
+        del dense
 
     # reference points, same kernels, not part of `value`: one lockstep group of 8 on one stream
     # (with per-stage device times undisturbed by concurrent groups) and a single volume
@@ -315,16 +350,6 @@ def main():
             single_step()
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t0) / 5 * 1e3
-        # reshape stage (the kernel north_star's ">= 50 % of the HBM-read roofline" refers to): read fraction of
-        # the tiled permute alone, from the one-group phase (nothing else on the GPU)
-        e = stages_group8.get("encode_permute", {})
-        perm_ms = e.get("ms_per_step", float("nan")) / max(e.get("launches_per_step", 1.0), 1.0)
-        roofline["reshape_stage"] = {
-            "kernel": "encode_tiled_kernel<uint32, vec>",
-            "launch_us": perm_ms * 1e3,
-            "read_frac": (4 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
-            "read_write_frac": (8 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
-        }
 
     line = {
         "metric": METRIC,

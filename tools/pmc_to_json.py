@@ -16,8 +16,8 @@ import json
 import os
 import sys
 
-DOUBLE_FETCH = ("trd_column_kernel",)  # double2 (16 B / lane) loads of the trailing matrix
-KEEP = ("trd_column_kernel", "trd_tail_kernel", "trd_invit_kernel", "trd_back_kernel", "trd_bisect_kernel",
+DOUBLE_FETCH = ("trd_column_kernel", "gram128_kernel")  # 16 B / lane streaming loads (double2 / float4)
+KEEP = ("gram128_kernel", "gram128_reduce_kernel", "trd_team_kernel", "trd_column_kernel", "trd_tail_kernel", "trd_invit_kernel", "trd_back_kernel", "trd_bisect_kernel",
         "gram_wide_kernel", "encode_tiled_kernel", "decode_tiled_kernel", "gemm_kernel", "gemm_bf16_kernel")
 
 
