@@ -365,6 +365,12 @@ __device__ __forceinline__ void team_store(double* p, double v) {
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ unsigned long long team_poll(const unsigned long long* p) {
+  unsigned long long v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
 template <int NR>
 __global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0) {
   constexpr int CW = 32;             // columns per workgroup
@@ -392,7 +398,10 @@ __global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ 
   __shared__ double part[4][CW];
   __shared__ int go;
 
-  const int q = lane / LPR, p = lane % LPR;
+  // the RPW = 8 lanes that share a column group are ADJACENT (q fastest): the column sums fold with lane-xor 1, 2, 4,
+  // which are register moves inside a row of 16 lanes (xor 8 / 16 / 32 go through the LDS crossbar: 0.4 us per
+  // column); the matrix itself is loaded and stored once per launch, its coalescing does not matter
+  const int q = lane % RPW, p = lane / RPW;
   const int c = c0 + 4 * p;
   const int row0 = RPW * wave + q;
   double a[NT][4];
@@ -521,13 +530,13 @@ __global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ 
         const RowVec rec = rv[row0 + RPI * u];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          a[u][k] -= fma(rec.vp, wc[k], rec.wp * vc[k]);
+          a[u][k] = fma(-rec.wp, vc[k], fma(-rec.vp, wc[k], a[u][k]));
           acc[k] = fma(a[u][k], rec.vj, acc[k]);
         }
       }
     }
 #pragma unroll
-    for (int off = LPR; off < 64; off <<= 1)
+    for (int off = 1; off < RPW; off <<= 1)
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
     if (q == 0) {
@@ -571,18 +580,23 @@ __global__ void __launch_bounds__(256, 2) trd_team_kernel(TrdDesc* __restrict__ 
       int ok = 1;
       if (j < j_last) {
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(&sync->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          if (__hip_atomic_load(&sync->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            ok = 0;
-            break;
+        // the counter is polled through the scalar unit with the cache bypassed (0.47 us per hand-off between two
+        // workgroups, 0.65 with agent-scope vector loads: tools/scratch/xcc_probe.hip); the abort flag and the
+        // clock are looked at every 64th poll
+        unsigned polls = 0;
+        while (team_poll(&sync->count) < target) {
+          if ((++polls & 63u) == 0) {
+            if (__hip_atomic_load(&sync->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+              ok = 0;
+              break;
+            }
+            if (wall_clock64() - t0 > kTeamSpinTicks) {
+              __hip_atomic_store(&sync->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              d.status = 2;
+              ok = 0;
+              break;
+            }
           }
-          if (wall_clock64() - t0 > kTeamSpinTicks) {
-            __hip_atomic_store(&sync->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            d.status = 2;
-            ok = 0;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(4);
         }
       }
       go = ok;
