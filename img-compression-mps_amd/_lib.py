@@ -69,8 +69,16 @@ SIGNATURES = {
     "ndmps_chain_tail_columns": (i64, [C.c_int, p_i64]),
     "ndmps_plan_split_offsets": (C.c_int, [vp, i64, p_i64, p_i64]),
     "ndmps_chain_contract_scatter_f32": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), vp, vp, vp, vp, i64, vp, i64, vp]),
+    "ndmps_chain_batched_workspace_bytes": (i64, [C.c_int, C.c_int, p_i64, p_i64]),
     "ndmps_chain_contract_scatter_batched_f32": (C.c_int, [C.c_int, C.c_int, p_i64, p_i64, C.POINTER(vp), C.POINTER(vp), vp, vp, vp,
                                                            i64, vp, i64, vp]),
+    "ndmps_gemm_batched_max": (C.c_int, []),
+    "ndmps_sgemm_batched": (C.c_int, [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.POINTER(vp), i64, C.POINTER(vp), i64,
+                                      C.POINTER(vp), i64, vp]),
+    "ndmps_dgemm_batched": (C.c_int, [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.POINTER(vp), i64, C.POINTER(vp), i64,
+                                      C.POINTER(vp), i64, vp]),
+    "ndmps_sgemm_indexed_batched": (C.c_int, [C.c_int, i64, i64, i64, C.POINTER(vp), i64, vp, vp, C.c_int, C.POINTER(vp), i64,
+                                              C.POINTER(vp), i64, vp, vp, vp]),
     "ndmps_sgemm_indexed": (C.c_int, [i64, i64, i64, vp, i64, vp, vp, C.c_int, vp, i64, vp, i64, vp, vp, vp]),
     "ndmps_chain_contract_bf16": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), vp, vp, i64, vp]),
     "ndmps_syevj_workspace_bytes": (i64, [i64]),

@@ -538,17 +538,11 @@ class NDMPS:
             out = torch.empty((batch,) + tuple(first._shape), dtype=torch.float32, device=device)
             bonds = (C.c_int64 * (batch * (L + 1)))()
             cores = (C.c_void_p * (batch * L))()
-            ws_bytes = 0
-            seen = {}
             for b, o in enumerate(objs):
-                bl = o.mps.bonds
-                bonds[b * (L + 1): (b + 1) * (L + 1)] = bl
+                bonds[b * (L + 1): (b + 1) * (L + 1)] = o.mps.bonds
                 for i, c in enumerate(o.mps.cores):
                     cores[b * L + i] = c.data_ptr()
-                key = tuple(bl)
-                if key not in seen:
-                    seen[key] = int(lib.ndmps_chain_workspace_bytes(L, cdims, _lib.i64_array(bl)))
-                ws_bytes = max(ws_bytes, seen[key])
+            ws_bytes = int(lib.ndmps_chain_batched_workspace_bytes(batch, L, cdims, bonds))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
             base, step = out.data_ptr(), plan.numel * 4
             outs = (C.c_void_p * batch)(*[base + b * step for b in range(batch)])

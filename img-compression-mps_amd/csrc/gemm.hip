@@ -86,10 +86,18 @@ struct GemmIndex {
   const int64_t* c_col;
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool VEC, bool IDX = false>
-__global__ void __launch_bounds__(256, 2)
-gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
-            const T* __restrict__ B, int64_t ldb, T* __restrict__ C, int64_t ldc, GemmIndex ix = GemmIndex()) {
+// operands of a batch of products of one shape: product blockIdx.z uses a[z], b[z], c[z] (kernel arguments)
+constexpr int kGemmMaxBatch = 64;
+struct GemmBatchPtrs {
+  const void* a[kGemmMaxBatch];
+  const void* b[kGemmMaxBatch];
+  void* c[kGemmMaxBatch];
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool VEC, bool IDX>
+__device__ __forceinline__ void
+gemm_body(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+          T* __restrict__ C, int64_t ldc, const GemmIndex& ix) {
   using MF = Mfma<T>;
   constexpr int BK = 16;
   constexpr int MT = MF::MT;
@@ -285,18 +293,47 @@ gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t ld
     }
 }
 
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool VEC, bool IDX = false>
+__global__ void __launch_bounds__(256, 2)
+gemm_kernel(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
+            const T* __restrict__ B, int64_t ldb, T* __restrict__ C, int64_t ldc, GemmIndex ix = GemmIndex()) {
+  gemm_body<T, BM, BN, WAVES_M, WAVES_N, TA, TB, VEC, IDX>(M, N, K, A, lda, B, ldb, C, ldc, ix);
+}
+
+// the same product for every operand triple of a batch (grid.z): what a lockstep group of volumes needs at a site
+// of the sweep or a stage of the chain -- one launch instead of one per volume
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, bool VEC, bool IDX = false>
+__global__ void __launch_bounds__(256, 2)
+gemm_batched_kernel(int64_t M, int64_t N, int64_t K, GemmBatchPtrs p, int64_t lda, int64_t ldb, int64_t ldc,
+                    GemmIndex ix = GemmIndex()) {
+  gemm_body<T, BM, BN, WAVES_M, WAVES_N, TA, TB, VEC, IDX>(M, N, K, static_cast<const T*>(p.a[blockIdx.z]), lda,
+                                                           static_cast<const T*>(p.b[blockIdx.z]), ldb,
+                                                           static_cast<T*>(p.c[blockIdx.z]), ldc, ix);
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_gemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const T* A, int64_t lda,
-                const T* B, int64_t ldb, T* C, int64_t ldc, hipStream_t stream) {
-  dim3 grid((unsigned)ndmps::ceil_div(m, BM), (unsigned)ndmps::ceil_div(n, BN));
+                const T* B, int64_t ldb, T* C, int64_t ldc, hipStream_t stream, const GemmBatchPtrs* bp = nullptr,
+                int batch = 1) {
+  dim3 grid((unsigned)ndmps::ceil_div(m, BM), (unsigned)ndmps::ceil_div(n, BN), (unsigned)batch);
   dim3 block(256);
   // vector path: whole quads are either inside or outside every bound, and 4-element aligned
   const uintptr_t al = sizeof(T) * 4;
-  const bool vec = lda % 4 == 0 && ldb % 4 == 0 && k % 4 == 0 && (!transA || m % 4 == 0) &&
-                   (transB || n % 4 == 0) && (uintptr_t)A % al == 0 && (uintptr_t)B % al == 0;
-#define NDMPS_GEMM_LAUNCH(TA_, TB_, V_)                                                                 \
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TA_, TB_, V_>), grid, block, 0, stream, \
-                     m, n, k, A, lda, B, ldb, C, ldc)
+  bool vec = lda % 4 == 0 && ldb % 4 == 0 && k % 4 == 0 && (!transA || m % 4 == 0) && (transB || n % 4 == 0);
+  if (bp) {
+    for (int z = 0; z < batch; ++z) vec = vec && (uintptr_t)bp->a[z] % al == 0 && (uintptr_t)bp->b[z] % al == 0;
+  } else {
+    vec = vec && (uintptr_t)A % al == 0 && (uintptr_t)B % al == 0;
+  }
+#define NDMPS_GEMM_LAUNCH(TA_, TB_, V_)                                                                            \
+  do {                                                                                                              \
+    if (bp)                                                                                                         \
+      hipLaunchKernelGGL((gemm_batched_kernel<T, BM, BN, WAVES_M, WAVES_N, TA_, TB_, V_>), grid, block, 0, stream,  \
+                         m, n, k, *bp, lda, ldb, ldc);                                                              \
+    else                                                                                                            \
+      hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TA_, TB_, V_>), grid, block, 0, stream, m, n, k,  \
+                         A, lda, B, ldb, C, ldc);                                                                   \
+  } while (0)
 #define NDMPS_GEMM_TRANS(V_)                                     \
   do {                                                           \
     if (transA && transB) NDMPS_GEMM_LAUNCH(true, true, V_);     \
@@ -991,6 +1028,97 @@ extern "C" int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t
   if (n <= 32 || m <= 32)
     return launch_gemm<double, 32, 32, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
   return launch_gemm<double, 64, 64, 2, 2>(transA, transB, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, s);
+}
+
+namespace {
+template <typename T>
+int gemm_batched_check(int batch, const T* const* h_A, const T* const* h_B, T* const* h_C, GemmBatchPtrs& bp) {
+  NDMPS_REQUIRE(batch >= 1 && batch <= kGemmMaxBatch && h_A && h_B && h_C, "batched GEMM: batch=%d outside [1, %d] or NULL array",
+                batch, kGemmMaxBatch);
+  for (int z = 0; z < batch; ++z) {
+    NDMPS_REQUIRE(h_A[z] && h_B[z] && h_C[z], "batched GEMM: NULL operand %d", z);
+    bp.a[z] = h_A[z];
+    bp.b[z] = h_B[z];
+    bp.c[z] = h_C[z];
+  }
+  return NDMPS_OK;
+}
+}  // namespace
+
+// `batch` (<= ndmps_gemm_batched_max()) products of one shape in one launch; h_A / h_B / h_C: HOST arrays of device
+// pointers.  Same tiles and arithmetic as ndmps_sgemm / ndmps_dgemm on each triple.
+extern "C" int ndmps_gemm_batched_max(void) { return kGemmMaxBatch; }
+
+extern "C" int ndmps_sgemm_batched(int batch, int transA, int transB, int64_t m, int64_t n, int64_t k,
+                                   const float* const* h_A, int64_t lda, const float* const* h_B, int64_t ldb,
+                                   float* const* h_C, int64_t ldc, ndmps_stream_t stream) {
+  GemmBatchPtrs bp;
+  NDMPS_TRY(gemm_batched_check(batch, h_A, h_B, h_C, bp));
+  NDMPS_TRY(gemm_check(m, n, k, h_A[0], lda, transA, h_B[0], ldb, transB, h_C[0], ldc));
+  if (m == 0 || n == 0) return NDMPS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const float* A = nullptr;
+  float* Cn = nullptr;
+  if (n <= 32) return launch_gemm<float, 128, 32, 4, 1>(transA, transB, m, n, k, A, lda, A, ldb, Cn, ldc, s, &bp, batch);
+  if (n <= 64 || m <= 64)
+    return launch_gemm<float, 64, 64, 2, 2>(transA, transB, m, n, k, A, lda, A, ldb, Cn, ldc, s, &bp, batch);
+  return launch_gemm<float, 128, 128, 2, 2>(transA, transB, m, n, k, A, lda, A, ldb, Cn, ldc, s, &bp, batch);
+}
+
+extern "C" int ndmps_dgemm_batched(int batch, int transA, int transB, int64_t m, int64_t n, int64_t k,
+                                   const double* const* h_A, int64_t lda, const double* const* h_B, int64_t ldb,
+                                   double* const* h_C, int64_t ldc, ndmps_stream_t stream) {
+  GemmBatchPtrs bp;
+  NDMPS_TRY(gemm_batched_check(batch, h_A, h_B, h_C, bp));
+  NDMPS_TRY(gemm_check(m, n, k, h_A[0], lda, transA, h_B[0], ldb, transB, h_C[0], ldc));
+  if (m == 0 || n == 0) return NDMPS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const double* A = nullptr;
+  double* Cn = nullptr;
+  if (n <= 16) return launch_gemm<double, 64, 16, 4, 1>(transA, transB, m, n, k, A, lda, A, ldb, Cn, ldc, s, &bp, batch);
+  if (n <= 32 || m <= 32)
+    return launch_gemm<double, 32, 32, 2, 2>(transA, transB, m, n, k, A, lda, A, ldb, Cn, ldc, s, &bp, batch);
+  return launch_gemm<double, 64, 64, 2, 2>(transA, transB, m, n, k, A, lda, A, ldb, Cn, ldc, s, &bp, batch);
+}
+
+// batched C = A B with table-driven addressing (one set of tables for the whole batch: the volumes of a lockstep
+// group share the index permutation); see ndmps_sgemm_indexed
+extern "C" int ndmps_sgemm_indexed_batched(int batch, int64_t m, int64_t n, int64_t k, const float* const* h_A,
+                                           int64_t lda, const int64_t* d_a_row, const int64_t* d_a_col, int a_vec4,
+                                           const float* const* h_B, int64_t ldb, float* const* h_C, int64_t ldc,
+                                           const int64_t* d_c_row, const int64_t* d_c_col, ndmps_stream_t stream) {
+  GemmBatchPtrs bp;
+  NDMPS_TRY(gemm_batched_check(batch, h_A, h_B, h_C, bp));
+  NDMPS_REQUIRE(m >= 0 && n >= 0 && k >= 0, "bad indexed GEMM extent");
+  NDMPS_REQUIRE((d_a_row == nullptr) == (d_a_col == nullptr) && (d_c_row == nullptr) == (d_c_col == nullptr),
+                "offset tables come in (row, column) pairs");
+  NDMPS_REQUIRE(ldb >= n && (d_a_row || lda >= k) && (d_c_row || ldc >= n), "leading dimension too small");
+  if (m == 0 || n == 0) return NDMPS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GemmIndex ix{d_a_row, d_a_col, d_c_row, d_c_col};
+  const uintptr_t al = 16;
+  bool vec = ldb % 4 == 0 && k % 4 == 0 && n % 4 == 0 && (d_a_row ? a_vec4 != 0 : lda % 4 == 0);
+  for (int z = 0; z < batch; ++z) vec = vec && (uintptr_t)bp.a[z] % al == 0 && (uintptr_t)bp.b[z] % al == 0;
+  const dim3 block(256);
+  if (n <= 64 || m <= 64) {
+    const dim3 grid((unsigned)ndmps::ceil_div(m, 64), (unsigned)ndmps::ceil_div(n, 64), (unsigned)batch);
+    if (vec)
+      hipLaunchKernelGGL((gemm_batched_kernel<float, 64, 64, 2, 2, false, false, true, true>), grid, block, 0, s, m, n, k,
+                         bp, lda, ldb, ldc, ix);
+    else
+      hipLaunchKernelGGL((gemm_batched_kernel<float, 64, 64, 2, 2, false, false, false, true>), grid, block, 0, s, m, n,
+                         k, bp, lda, ldb, ldc, ix);
+  } else {
+    const dim3 grid((unsigned)ndmps::ceil_div(m, 128), (unsigned)ndmps::ceil_div(n, 128), (unsigned)batch);
+    if (vec)
+      hipLaunchKernelGGL((gemm_batched_kernel<float, 128, 128, 2, 2, false, false, true, true>), grid, block, 0, s, m, n,
+                         k, bp, lda, ldb, ldc, ix);
+    else
+      hipLaunchKernelGGL((gemm_batched_kernel<float, 128, 128, 2, 2, false, false, false, true>), grid, block, 0, s, m,
+                         n, k, bp, lda, ldb, ldc, ix);
+  }
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
 }
 
 // geometry of the 128-wide path: ~2 workgroups per CU, slabs a multiple of the 32-row chunk

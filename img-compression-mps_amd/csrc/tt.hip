@@ -1134,6 +1134,108 @@ extern "C" int ndmps_chain_contract_scatter_f32(int L, const int64_t* h_dims, co
 // The same for a list of MPS over the same sites (conv_to_tensors, evaluation/benchmark.py:80-100): volume b has
 // bonds h_bonds[b (L + 1) ..], cores h_cores[b L ..] and goes to h_out[b]; one workspace (sized for the largest
 // bonds) serves them in turn on `stream`.  The launches of all volumes are issued by this one call.
+namespace {
+struct PtrPairs {  // operands of a small per-volume kernel run for a whole batch (grid.y)
+  const void* in[64];
+  void* out[64];
+};
+__global__ void __launch_bounds__(256)
+gather_cols_batched_kernel(PtrPairs pp, int64_t rows, int64_t cols, const int32_t* __restrict__ perm) {
+  const float* in = static_cast<const float*>(pp.in[blockIdx.y]);
+  float* out = static_cast<float*>(pp.out[blockIdx.y]);
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    out[e] = in[(e / cols) * cols + perm[e % cols]];
+}
+
+// chain_impl<float> with the scatter epilogue for `count` (<= 64) MPS that share their bonds: every stage is one
+// batched launch (ndmps_sgemm_batched); volume b works in its own slice of the workspace.  Same products in the
+// same order as chain_impl on each volume: bit-identical results.
+int chain_batched_same_bonds(int count, int L, const int64_t* h_dims, const int64_t* h_bonds, const float* const* h_cores,
+                             float* const* h_out, const ChainScatter& sc, char* d_ws, int64_t ws_each, hipStream_t s) {
+  const ChainPlan p = chain_plan(L, h_dims, h_bonds);
+  const int j0 = p.j0;
+  NDMPS_REQUIRE(L >= 2 && j0 < L, "internal: batched chain needs a pre-contracted tail");
+  std::vector<const float*> A(count), B(count);
+  std::vector<float*> Cc(count);
+  std::vector<float*> ws_left(count), ws_tail0(count), ws_tail1(count);
+  for (int b = 0; b < count; ++b) {
+    ws_left[b] = (float*)(d_ws + (int64_t)b * ws_each);
+    ws_tail0[b] = ws_left[b] + ndmps::round_up(p.left_elems, 64);
+    ws_tail1[b] = ws_tail0[b] + ndmps::round_up(p.tail_elems, 64);
+  }
+  // ---- tail, right to left
+  std::vector<const float*> R(count);
+  for (int b = 0; b < count; ++b) R[b] = h_cores[(int64_t)b * L + L - 1];
+  int64_t n_tail = h_dims[L - 1];
+  int t = 0;
+  for (int i = L - 2; i >= j0; --i) {
+    for (int b = 0; b < count; ++b) {
+      A[b] = h_cores[(int64_t)b * L + i];
+      B[b] = R[b];
+      Cc[b] = t == 0 ? ws_tail0[b] : ws_tail1[b];
+    }
+    NDMPS_TRY(ndmps_sgemm_batched(count, 0, 0, h_bonds[i] * h_dims[i], n_tail, h_bonds[i + 1], A.data(), h_bonds[i + 1],
+                                  B.data(), n_tail, Cc.data(), n_tail, s));
+    for (int b = 0; b < count; ++b) R[b] = Cc[b];
+    t ^= 1;
+    n_tail *= h_dims[i];
+  }
+  // ---- left part, cumulative; the product before the final one must land in the workspace
+  const int last_left = j0 - 1;
+  std::vector<const float*> left(count);
+  for (int b = 0; b < count; ++b) left[b] = h_cores[(int64_t)b * L];
+  int64_t rows = h_dims[0];
+  for (int i = 1; i <= last_left; ++i) {
+    const int64_t chi = h_bonds[i], cols = h_dims[i] * h_bonds[i + 1];
+    const int remaining = (last_left - i) + 1;
+    for (int b = 0; b < count; ++b) {
+      A[b] = left[b];
+      B[b] = h_cores[(int64_t)b * L + i];
+      Cc[b] = remaining % 2 == 0 ? h_out[b] : ws_left[b];
+    }
+    NDMPS_TRY(ndmps_sgemm_batched(count, 0, 0, rows, cols, chi, A.data(), chi, B.data(), cols, Cc.data(), cols, s));
+    for (int b = 0; b < count; ++b) left[b] = Cc[b];
+    rows *= h_dims[i];
+  }
+  NDMPS_REQUIRE(sc.n_cols == n_tail, "scatter tables are for %lld tail columns, the chain's tail has %lld",
+                (long long)sc.n_cols, (long long)n_tail);
+  // ---- final product: columns of R in memory order, every element straight to its voxel
+  PtrPairs pp;
+  for (int b = 0; b < count; ++b) {
+    float* spare = (R[b] == ws_tail0[b]) ? ws_tail1[b] : ws_tail0[b];
+    pp.in[b] = R[b];
+    pp.out[b] = spare;
+    A[b] = left[b];
+    B[b] = spare;
+    Cc[b] = h_out[b];
+  }
+  const int64_t k = h_bonds[j0];
+  hipLaunchKernelGGL(gather_cols_batched_kernel, dim3(grid1d(k * n_tail), count), dim3(256), 0, s, pp, k, n_tail,
+                     sc.col_perm);
+  NDMPS_LAUNCH_CHECK();
+  return ndmps_sgemm_indexed_batched(count, rows, n_tail, k, A.data(), k, nullptr, nullptr, 0, B.data(), n_tail, Cc.data(), 0,
+                                     sc.row_off, sc.col_off, s);
+}
+}  // namespace
+
+// The same for a list of MPS over the same sites (conv_to_tensors, evaluation/benchmark.py:80-100): volume b has
+// bonds h_bonds[b (L + 1) ..], cores h_cores[b L ..] and goes to h_out[b].  MPS that share their bonds (a lockstep
+// group whose caps bind) go through the chain TOGETHER, one batched launch per stage, each in its own slice of
+// d_ws (ndmps_chain_batched_workspace_bytes); otherwise the volumes are contracted in turn.  Bit-identical to
+// ndmps_chain_contract_scatter_f32 on each volume either way.
+extern "C" int64_t ndmps_chain_batched_workspace_bytes(int batch, int L, const int64_t* h_dims, const int64_t* h_bonds) {
+  if (batch < 1 || L < 1 || !h_dims || !h_bonds) return 0;
+  int64_t each = 0;
+  bool same = true;
+  for (int b = 0; b < batch; ++b) {
+    each = std::max(each, ndmps_chain_workspace_bytes(L, h_dims, h_bonds + (int64_t)b * (L + 1)));
+    for (int i = 0; i <= L; ++i) same = same && h_bonds[(int64_t)b * (L + 1) + i] == h_bonds[i];
+  }
+  each = ndmps::round_up(each, 256);
+  return same ? each * std::min(batch, 64) : each;
+}
+
 extern "C" int ndmps_chain_contract_scatter_batched_f32(int batch, int L, const int64_t* h_dims, const int64_t* h_bonds,
                                                         const float* const* h_cores, float* const* h_out,
                                                         const int64_t* d_row_off, const int64_t* d_col_off,
@@ -1142,6 +1244,37 @@ extern "C" int ndmps_chain_contract_scatter_batched_f32(int batch, int L, const 
   NDMPS_REQUIRE(batch >= 1 && L >= 1 && h_bonds && h_cores && h_out, "bad batched chain argument");
   NDMPS_REQUIRE(d_row_off && d_col_off && d_col_perm && n_cols >= 1, "NULL scatter table");
   ChainScatter sc{d_row_off, d_col_off, d_col_perm, n_cols};
+  bool same = batch > 1 && L >= 2;
+  for (int b = 1; b < batch && same; ++b)
+    for (int i = 0; i <= L; ++i) same = same && h_bonds[(int64_t)b * (L + 1) + i] == h_bonds[i];
+  const int64_t each = ndmps::round_up(ndmps_chain_workspace_bytes(L, h_dims, h_bonds), 256);
+  if (same && chain_plan(L, h_dims, h_bonds).j0 < L && d_ws && ws_bytes >= each * std::min(batch, 64)) {
+    // validate once through the single-volume entry's checks (bonds, operands) on volume 0 without launching
+    for (int b = 0; b < batch; ++b) {
+      NDMPS_REQUIRE(h_out[b], "NULL output %d", b);
+      for (int i = 0; i < L; ++i) NDMPS_REQUIRE(h_cores[(int64_t)b * L + i], "core %d of volume %d is NULL", i, b);
+    }
+    {
+      int64_t numel = 1, left = 1;
+      NDMPS_REQUIRE(h_bonds[0] == 1 && h_bonds[L] == 1, "open boundary bonds must be 1");
+      for (int i = 0; i < L; ++i) {
+        NDMPS_REQUIRE(h_dims[i] >= 1, "dims[%d] must be positive", i);
+        numel *= h_dims[i];
+      }
+      for (int i = 0; i < L; ++i) {
+        left *= h_dims[i];
+        NDMPS_REQUIRE(h_bonds[i + 1] >= 1 && h_bonds[i + 1] <= left && h_bonds[i + 1] <= numel / left,
+                      "bond %d = %lld exceeds min(%lld, %lld), the rank any unfolding can have", i + 1,
+                      (long long)h_bonds[i + 1], (long long)left, (long long)(numel / left));
+      }
+    }
+    for (int base = 0; base < batch; base += 64) {
+      const int count = std::min(64, batch - base);
+      NDMPS_TRY(chain_batched_same_bonds(count, L, h_dims, h_bonds, h_cores + (int64_t)base * L, h_out + base, sc,
+                                         (char*)d_ws, each, (hipStream_t)stream));
+    }
+    return NDMPS_OK;
+  }
   for (int b = 0; b < batch; ++b)
     NDMPS_TRY(chain_impl<float>(L, h_dims, h_bonds + (int64_t)b * (L + 1), h_cores + (int64_t)b * L, h_out[b], d_ws,
                                 ws_bytes, stream, &sc));

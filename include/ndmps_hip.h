@@ -128,6 +128,21 @@ int ndmps_sgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const f
 int ndmps_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const double* d_A,
                 int64_t lda, const double* d_B, int64_t ldb, double* d_C, int64_t ldc,
                 ndmps_stream_t stream);
+
+/* `batch` (<= ndmps_gemm_batched_max()) products of one shape in ONE launch: h_A / h_B / h_C are HOST arrays of
+ * device pointers (the reference multiplies volume by volume in a Python loop, evaluation/benchmark.py:73-100);
+ * same tiles and arithmetic as ndmps_sgemm / ndmps_dgemm / ndmps_sgemm_indexed on each triple. */
+int ndmps_gemm_batched_max(void);
+int ndmps_sgemm_batched(int batch, int transA, int transB, int64_t m, int64_t n, int64_t k, const float* const* h_A,
+                        int64_t lda, const float* const* h_B, int64_t ldb, float* const* h_C, int64_t ldc,
+                        ndmps_stream_t stream);
+int ndmps_dgemm_batched(int batch, int transA, int transB, int64_t m, int64_t n, int64_t k, const double* const* h_A,
+                        int64_t lda, const double* const* h_B, int64_t ldb, double* const* h_C, int64_t ldc,
+                        ndmps_stream_t stream);
+int ndmps_sgemm_indexed_batched(int batch, int64_t m, int64_t n, int64_t k, const float* const* h_A, int64_t lda,
+                                const int64_t* d_a_row, const int64_t* d_a_col, int a_vec4, const float* const* h_B,
+                                int64_t ldb, float* const* h_C, int64_t ldc, const int64_t* d_c_row,
+                                const int64_t* d_c_col, ndmps_stream_t stream);
 /* G(n,n) fp64 = A^T A for A (m,n) fp32 row-major; products exact, fp64 accumulation */
 int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n);
 int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t lda, double* d_G,
@@ -322,7 +337,10 @@ int ndmps_chain_contract_scatter_f32(int L, const int64_t* h_dims, const int64_t
                                      int64_t ws_bytes, ndmps_stream_t stream);
 /* The same for a list of MPS over the same sites (the reference reconstructs a list with a Python loop,
  * evaluation/benchmark.py:80-100): volume b has bonds h_bonds[b (L + 1) ..], cores h_cores[b L ..] and is written
- * to h_out[b]; d_ws (>= ndmps_chain_workspace_bytes of the largest bonds) serves the volumes in turn. */
+ * to h_out[b].  MPS that share their bonds go through the chain together (one batched launch per stage, each in
+ * its own slice of d_ws); otherwise the volumes are contracted in turn.  d_ws >=
+ * ndmps_chain_batched_workspace_bytes(batch, L, dims, bonds). */
+int64_t ndmps_chain_batched_workspace_bytes(int batch, int L, const int64_t* h_dims, const int64_t* h_bonds);
 int ndmps_chain_contract_scatter_batched_f32(int batch, int L, const int64_t* h_dims, const int64_t* h_bonds,
                                              const float* const* h_cores, float* const* h_out,
                                              const int64_t* d_row_off, const int64_t* d_col_off,

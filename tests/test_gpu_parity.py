@@ -801,6 +801,9 @@ def test_to_tensors_equals_to_tensor_per_object(shape, chi, mode, count):
     vols = [synthetic_mri(shape, seed=40 + i) if min(shape) > 8 else
             np.random.default_rng(40 + i).random(shape).astype(np.float32) for i in range(count)]
     objs = NDMPS.from_tensors(vols, mode=mode, max_bond=chi)
+    # equal bonds (the caps bind): the whole list goes through the chain together, one batched launch per stage
+    for a, b in zip([o.to_tensor(as_torch=True) for o in objs], NDMPS.to_tensors(objs, as_torch=True)):
+        assert torch.equal(a, b)
     objs[-1].compress(0.05)
     assert objs[-1].bond_sizes() != objs[0].bond_sizes() or chi is None or not objs[0].bond_sizes()  # (7, 11, 13): one site
     one_by_one = [o.to_tensor(as_torch=True) for o in objs]
