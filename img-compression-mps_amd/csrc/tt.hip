@@ -105,6 +105,64 @@ __global__ void __launch_bounds__(256) sqrt_clamp_kernel(const double* __restric
     s[i] = sqrt(fmax(w[i], 0.0));
 }
 
+// ---- the same small kernels for a whole lockstep group (blockIdx.y = volume): fp64 side arrays are strided in the
+//      workspace, volumes / carried matrices / cores come as pointers in the kernel arguments
+constexpr int kSmallBatch = 64;
+struct BatchOps {
+  const void* in[kSmallBatch];
+  void* out[kSmallBatch];
+};
+template <typename T>
+__global__ void __launch_bounds__(256) f32_to_f64_batched_kernel(BatchOps ops, int64_t n, double* __restrict__ y, int64_t y_stride) {
+  const T* x = static_cast<const T*>(ops.in[blockIdx.y]);
+  double* yb = y + (int64_t)blockIdx.y * y_stride;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) yb[i] = (double)(float)x[i];
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+core_from_vectors_batched_kernel(const double* __restrict__ V, int64_t v_stride, int64_t n, int64_t k, BatchOps ops) {
+  const double* Vb = V + (int64_t)blockIdx.y * v_stride;
+  T* core = static_cast<T*>(ops.out[blockIdx.y]);
+  const int64_t total = k * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / n, c = e % n;
+    core[e] = (T)(float)Vb[c * n + i];
+  }
+}
+__global__ void __launch_bounds__(256)
+sqrt_clamp_batched_kernel(const double* __restrict__ w, int64_t stride, int64_t n, double* __restrict__ sg) {
+  const double* wb = w + (int64_t)blockIdx.y * stride;
+  double* sb = sg + (int64_t)blockIdx.y * stride;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) sb[i] = sqrt(fmax(wb[i], 0.0));
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+scale_cols_to_f32_batched_kernel(const double* __restrict__ M, int64_t m_stride, int64_t rows, int64_t ldm, int64_t k,
+                                 const double* __restrict__ sigma, int64_t s_stride, double power, BatchOps ops) {
+  const double* Mb = M + (int64_t)blockIdx.y * m_stride;
+  const double* sb = sigma + (int64_t)blockIdx.y * s_stride;
+  T* out = static_cast<T*>(ops.out[blockIdx.y]);
+  const int64_t total = rows * k;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / k, c = e % k;
+    const double sg = sb[c];
+    out[e] = (T)(float)(sg > 0.0 ? Mb[r * ldm + c] * pow(sg, power) : 0.0);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+scale_rows_to_f32_batched_kernel(const double* __restrict__ M, int64_t m_stride, int64_t k, int64_t n,
+                                 const double* __restrict__ sigma, int64_t s_stride, double power, BatchOps ops) {
+  const double* Mb = M + (int64_t)blockIdx.y * m_stride;
+  const double* sb = sigma + (int64_t)blockIdx.y * s_stride;
+  T* out = static_cast<T*>(ops.out[blockIdx.y]);
+  const int64_t total = k * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const double sg = sb[e / n];
+    out[e] = (T)(float)(sg > 0.0 ? Mb[e] * pow(sg, power) : 0.0);
+  }
+}
+
 // ------------------------------------------------------------ merged trailing sites (bond-capped sweep)
 // While a bond is exact (the product N_{i+1} of the site dims to its right does not exceed the cap) site i's
 // unfolding is the RAW unfolding A_i (M_i x N_i) times a block-diagonal basis:  A_i (I_{d_i} (x) W_{i+1}),
@@ -208,7 +266,9 @@ unpermute_gram_kernel(const double* __restrict__ Gp, int64_t n, const int32_t* _
 // ... and the projection multiplies by the basis with its rows in memory order: out[c'] = W[perm[c']]
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ W, int64_t rows, int64_t cols, const int32_t* __restrict__ perm,
-                   float* __restrict__ out) {
+                   float* __restrict__ out, int64_t w_stride = 0, int64_t out_stride = 0) {  // volume blockIdx.y
+  W += (int64_t)blockIdx.y * w_stride;
+  out += (int64_t)blockIdx.y * out_stride;
   const int64_t total = rows * cols;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
     out[e] = W[(int64_t)perm[e / cols] * cols + e % cols];
@@ -351,7 +411,7 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
   used = arena_bytes(used, 1, eig_workspace_bytes(out.small_max, batch, max_bond));
   used = arena_bytes(used, 1, out.gram_ws);                             // shared, stream-ordered
   used = arena_bytes(used, 8, (int64_t)batch * out.wide_elems);         // A64 per volume
-  used = arena_bytes(used, 8, out.wide_elems);                          // U_k^T A64, shared
+  used = arena_bytes(used, 8, (int64_t)batch * out.wide_elems);         // U_k^T A64 per volume
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_n);      // raw Gram of the merged run
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_n);      // T = Graw B
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_w);      // accumulated basis W (ping)
@@ -428,6 +488,17 @@ inline int gemm_T(int transB, int64_t m, int64_t n, int64_t k, const __bf16* A, 
   return ndmps_gemm_bf16(transB, m, n, k, A, k, B, ldb, C, n, tws, tws_bytes, s);
 }
 
+// products of a whole lockstep group in one launch (fp32 storage; bf16 storage goes volume by volume)
+inline bool gemm_batched_T(int batch, int transB, int64_t m, int64_t n, int64_t k, float* const* A, float* const* B,
+                           int64_t ldb, float* const* C, hipStream_t s, int* rc) {
+  if (batch > ndmps_gemm_batched_max()) return false;
+  *rc = ndmps_sgemm_batched(batch, 0, transB, m, n, k, (const float* const*)A, k, (const float* const*)B, ldb, C, n, s);
+  return true;
+}
+inline bool gemm_batched_T(int, int, int64_t, int64_t, int64_t, __bf16* const*, __bf16* const*, int64_t, __bf16* const*,
+                           hipStream_t, int*) {
+  return false;
+}
 // fp32 only: Gram and projection of the merged run through the permutation tables
 inline int gram_src(const float* vol, int64_t m, int64_t n, const SweepSource& src, double* G, void* ws, int64_t wsb,
                     hipStream_t s) {
@@ -474,7 +545,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
   char* ev_ws = ar.take<char>(ev_ws_bytes);
   char* gram_ws = ar.take<char>(lay.gram_ws);
   double* A64 = ar.take<double>((int64_t)batch * lay.wide_elems);
-  double* UtA = ar.take<double>(lay.wide_elems);
+  double* UtA = ar.take<double>((int64_t)batch * lay.wide_elems);
   NDMPS_REQUIRE(other && G && V && w && sig && ev_ws && gram_ws && A64 && UtA, "workspace carve failed");
 
   double* Graw = ar.take<double>((int64_t)batch * lay.merge_n * lay.merge_n);
@@ -567,6 +638,20 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     return NDMPS_OK;
   };
 
+  // every volume in the same state (always so when the ranks are decided on the device): the per-volume launches of
+  // a site become one launch each
+  auto uniform = [&]() {
+    if (batch < 2) return false;
+    for (int b = 1; b < batch; ++b)
+      if (chi_r[b] != chi_r[0] || cur_elems[b] != cur_elems[0]) return false;
+    return true;
+  };
+  auto uniform_kept = [&]() {
+    for (int b = 1; b < batch; ++b)
+      if (kept[b] != kept[0] || eig_n[b] != eig_n[0]) return false;
+    return true;
+  };
+
   int i_start = L - 1;
   if (lay.merge_from < L) {
     // ---- merged trailing run: sites merge_from .. L-1 from ONE Gram pass and ONE projection pass
@@ -638,18 +723,54 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
                            i == i0 ? W32 + base * stride_w : (T*)nullptr, stride_w, (int)n_right, (int)d_i, rk);
       }
       NDMPS_LAUNCH_CHECK();
+      if (batch > 1 && uniform_kept()) {
+        for (int base = 0; base < batch; base += kSmallBatch) {
+          const int count = std::min(kSmallBatch, batch - base);
+          BatchOps ops;
+          for (int t = 0; t < count; ++t) ops.out[t] = h_cores[base + t] + h_core_offsets[i];
+          hipLaunchKernelGGL(core_from_vectors_batched_kernel<T>, dim3(grid1d(kept[0] * eig_n[0]), count), dim3(256), 0, s,
+                             V + (int64_t)base * sq, sq, eig_n[0], kept[0], ops);
+        }
+      } else {
+        for (int b = 0; b < batch; ++b)
+          hipLaunchKernelGGL(core_from_vectors_kernel<T>, dim3(grid1d(kept[b] * eig_n[b])), dim3(256), 0, s,
+                             V + (int64_t)b * sq, eig_n[b], kept[b], h_cores[b] + h_core_offsets[i]);
+      }
       for (int b = 0; b < batch; ++b) {
-        const int64_t n = eig_n[b], k = kept[b];
-        hipLaunchKernelGGL(core_from_vectors_kernel<T>, dim3(grid1d(k * n)), dim3(256), 0, s, V + (int64_t)b * sq, n, k,
-                           h_cores[b] + h_core_offsets[i]);
-        chi_r[b] = k;
-        h_bonds_out[(int64_t)b * (L + 1) + i] = k;
+        chi_r[b] = kept[b];
+        h_bonds_out[(int64_t)b * (L + 1) + i] = kept[b];
       }
       NDMPS_LAUNCH_CHECK();
       wcur ^= 1;
       n_right = n_i;
     }
-    for (int b = 0; b < batch; ++b) {  // carry = A_raw W (m0 x k)
+    bool projected = false;
+    if (src && uniform() && batch <= ndmps_gemm_batched_max()) {
+      // carry = A_raw W for the whole group: the basis rows into memory order (one launch), then one batched product
+      // that reads the volumes through the permutation tables
+      const int64_t k = chi_r[0];
+      float* wperm0 = reinterpret_cast<float*>(Tm);
+      const int64_t wperm_stride = stride_top * 2;  // fp64 slots of T, in floats
+      hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d(n0 * k), batch), dim3(256), 0, s, (const float*)W32, n0, k,
+                         src->col_perm, wperm0, stride_w, wperm_stride);
+      NDMPS_LAUNCH_CHECK();
+      std::vector<const float*> pa(batch), pb(batch);
+      std::vector<float*> pc(batch);
+      for (int b = 0; b < batch; ++b) {
+        pa[b] = (const float*)cur[b];
+        pb[b] = wperm0 + (int64_t)b * wperm_stride;
+        pc[b] = (float*)nxt[b];
+      }
+      NDMPS_TRY(ndmps_sgemm_indexed_batched(batch, m0, k, n0, pa.data(), 0, src->row_off, src->col_off, 1, pb.data(), k,
+                                            pc.data(), k, nullptr, nullptr, s));
+      for (int b = 0; b < batch; ++b) {
+        cur[b] = nxt[b];
+        nxt[b] = nxt[b] + lay.numel / 2;
+        cur_elems[b] = m0 * k;
+      }
+      projected = true;
+    }
+    for (int b = 0; b < batch && !projected; ++b) {  // carry = A_raw W (m0 x k)
       const int64_t k = chi_r[b];
       if (src) {
         // T (fp64 scratch of the congruences, free now) holds the basis with its rows in memory order
@@ -682,7 +803,30 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
         NDMPS_TRY(gram_batched_T(batch, cur.data(), m, n, G, sq, gram_ws, lay.gram_ws, s));
       }
     }
-    for (int b = 0; b < batch && !together; ++b) {
+    // wide unfoldings (n > m, the last sites) of a uniform group: A A^T of every volume from two launches
+    const bool uni = uniform() && batch <= std::min(kSmallBatch, ndmps_gemm_batched_max());
+    bool wide_together = false;
+    if (!together && uni) {
+      const int64_t n = h_dims[i] * chi_r[0];
+      m = cur_elems[0] / n;
+      if (n > m) {
+        BatchOps ops;
+        std::vector<const double*> pa(batch);
+        std::vector<double*> pc(batch);
+        for (int b = 0; b < batch; ++b) {
+          ops.in[b] = cur[b];
+          pa[b] = A64 + (int64_t)b * lay.wide_elems;
+          pc[b] = G + (int64_t)b * sq;
+          eig_n[b] = m;
+        }
+        hipLaunchKernelGGL(f32_to_f64_batched_kernel<T>, dim3(grid1d(m * n), batch), dim3(256), 0, s, ops, m * n, A64,
+                           lay.wide_elems);
+        NDMPS_LAUNCH_CHECK();
+        NDMPS_TRY(ndmps_dgemm_batched(batch, 0, 1, m, m, n, pa.data(), n, pa.data(), n, pc.data(), m, s));
+        wide_together = true;
+      }
+    }
+    for (int b = 0; b < batch && !together && !wide_together; ++b) {
       const int64_t n = h_dims[i] * chi_r[b];
       m = cur_elems[b] / n;
       eig_n[b] = std::min(m, n);
@@ -700,9 +844,58 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       }
     }
     NDMPS_TRY(solve_site(i));
-    // ---- core and carried matrix per volume
-    for (int b = 0; b < batch; ++b) {
+    // ---- core and carried matrix: one launch per step for a uniform group, else volume by volume
+    bool done = false;
+    if (uni && uniform_kept()) {
+      const int64_t n = h_dims[i] * chi_r[0], small = eig_n[0], k = kept[0];
+      BatchOps cores_out, carry_out;
+      std::vector<T*> pcur(batch), pcore(batch), pnxt(batch);
+      for (int b = 0; b < batch; ++b) {
+        pcur[b] = cur[b];
+        pcore[b] = h_cores[b] + h_core_offsets[i];
+        pnxt[b] = nxt[b];
+        cores_out.out[b] = pcore[b];
+        carry_out.out[b] = nxt[b];
+      }
+      if (n <= m) {
+        int rc = NDMPS_OK;
+        hipLaunchKernelGGL(core_from_vectors_batched_kernel<T>, dim3(grid1d(k * n), batch), dim3(256), 0, s, V, sq, n, k,
+                           cores_out);
+        NDMPS_LAUNCH_CHECK();
+        done = gemm_batched_T(batch, 1, m, k, n, pcur.data(), pcore.data(), n, pnxt.data(), s, &rc);
+        NDMPS_TRY(rc);
+        if (!done)  // bf16 storage: the products go volume by volume
+          for (int b = 0; b < batch; ++b) NDMPS_TRY(gemm_T(1, m, k, n, cur[b], pcore[b], n, nxt[b], tws, tws_bytes, s));
+        done = true;
+      } else {
+        std::vector<const double*> pv(batch), pa(batch);
+        std::vector<double*> pu(batch);
+        for (int b = 0; b < batch; ++b) {
+          pv[b] = V + (int64_t)b * sq;
+          pa[b] = A64 + (int64_t)b * lay.wide_elems;
+          pu[b] = UtA + (int64_t)b * lay.wide_elems;
+        }
+        hipLaunchKernelGGL(sqrt_clamp_batched_kernel, dim3(grid1d(small), batch), dim3(256), 0, s, w, lay.small_max, small,
+                           sig);
+        hipLaunchKernelGGL(scale_cols_to_f32_batched_kernel<T>, dim3(grid1d(m * k), batch), dim3(256), 0, s, V, sq, m, m, k,
+                           sig, lay.small_max, 1.0, carry_out);  // carry = U_k diag(sigma_k)
+        NDMPS_LAUNCH_CHECK();
+        NDMPS_TRY(ndmps_dgemm_batched(batch, 1, 0, k, n, m, pv.data(), m, pa.data(), n, pu.data(), n, s));
+        hipLaunchKernelGGL(scale_rows_to_f32_batched_kernel<T>, dim3(grid1d(k * n), batch), dim3(256), 0, s, UtA,
+                           lay.wide_elems, k, n, sig, lay.small_max, -1.0, cores_out);  // core = diag(1/sigma_k) U_k^T A
+        NDMPS_LAUNCH_CHECK();
+        done = true;
+      }
+      for (int b = 0; b < batch; ++b) {
+        std::swap(cur[b], nxt[b]);
+        cur_elems[b] = m * k;
+        chi_r[b] = k;
+        h_bonds_out[(int64_t)b * (L + 1) + i] = k;
+      }
+    }
+    for (int b = 0; b < batch && !done; ++b) {
       const int64_t n = h_dims[i] * chi_r[b];
+      m = cur_elems[b] / n;
       const int64_t small = eig_n[b];
       const int64_t k = kept[b];
       T* core = h_cores[b] + h_core_offsets[i];
