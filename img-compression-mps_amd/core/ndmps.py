@@ -190,6 +190,21 @@ class NDMPS:
         # that, ndmps.py:17-35), set by from_tensors / codec.loads otherwise
         self._shape = tuple(int(v) for v in np.shape(encoding_map)[:-1]) if encoding_map is not None else None
 
+    # singular values kept by the sweep, per bond (None for site 0); from_tensors stores them lazily
+    @property
+    def sweep_spectra(self):
+        lazy = self.__dict__.get("_spectra_lazy")
+        if lazy is not None:
+            row, offs, counts = lazy
+            self.__dict__["_sweep_spectra"] = [None] + [row[offs[i]: offs[i] + counts[i]].copy() for i in range(1, len(counts))]
+            self.__dict__["_spectra_lazy"] = None
+        return self.__dict__.get("_sweep_spectra")
+
+    @sweep_spectra.setter
+    def sweep_spectra(self, value):
+        self.__dict__["_spectra_lazy"] = None
+        self.__dict__["_sweep_spectra"] = value
+
     # The reference keeps the (*shape, L) int64 map; here it is built on first access only.
     @property
     def encoding_map(self):
@@ -262,7 +277,10 @@ class NDMPS:
                     raise ValueError("Shape cannot be empty.")
                 # the volume is only written to when it is normalised in place: copy then, otherwise
                 # a volume already resident on the device in the storage type is read where it lies
-                x = tensor.detach().to(device=device, dtype=store).contiguous()
+                if tensor.dtype == store and tensor.device == device and tensor.is_contiguous() and not tensor.requires_grad:
+                    x = tensor  # resident in the storage type already: read where it lies
+                else:
+                    x = tensor.detach().to(device=device, dtype=store).contiguous()
                 if norm and x.data_ptr() == tensor.data_ptr():
                     x = x.clone()
             else:
@@ -361,8 +379,8 @@ class NDMPS:
             for i in range(1, L):
                 lefts[i] = lefts[i - 1] * dims[i - 1]
             objs = []
+            bl0 = np.zeros((L, 2))
             for b in range(batch):
-                spec_list = [None] * L
                 kb = bonds_np[b]
                 if per_site is not None:
                     cores = [per_site[i][b] for i in range(L)]
@@ -378,13 +396,18 @@ class NDMPS:
                             view = arena_all[b, offs[i]: offs[i] + k0 * dims[i] * k1].view(k0, dims[i], k1)
                             # truncated arenas are compact, keep the views; exact sweeps own worst-case arenas
                             cores.append(view if mb else view.clone())
-                for i in range(1, L):
-                    cnt = min(lefts[i], dims[i] * int(kb[i + 1]))
-                    spec_list[i] = spec_np[b, spec_offs[i]: spec_offs[i] + cnt].copy()
-                obj = cls(DeviceMPS(cores, _trusted=True), plan.qubit_size.copy(), None, [[0.0, 0.0]] * L, norm, None,
-                          mode, len(shape))
+                obj = cls.__new__(cls)  # the fields of __init__, without its array conversions (32 objects per group)
+                obj.qubit_size = plan.qubit_size.copy()
+                obj._encoding_map = None
+                obj.mps = DeviceMPS(cores, _trusted=True)
+                obj.dim = len(shape)
+                obj.norm = norm
+                obj.norm_value = None
+                obj.mode = mode
+                obj.boundary_list = bl0
                 obj._shape = shape
-                obj.sweep_spectra = spec_list
+                # singular values of the sweep, cut out of the group's buffer on first use
+                obj._spectra_lazy = (spec_np[b], spec_offs, [min(lefts[i], dims[i] * int(kb[i + 1])) for i in range(L)])
                 objs.append(obj)
             with _span("state"):
                 # boundary_list (ndmps.py:75) and norm_value (ndmps.py:76) of every volume from one
@@ -393,8 +416,9 @@ class NDMPS:
                 # update_norm() evaluates the full overlap contraction like the reference.
                 all_cores = [c for o in objs for c in o.mps.cores]
                 mm, ss = _ft.minmax_many(all_cores, with_sumsq=True)
+                mm_np = np.asarray(mm, dtype=np.float64).reshape(batch, L, 2)
                 for b, o in enumerate(objs):
-                    o.boundary_list = np.array([list(v) for v in mm[b * L:(b + 1) * L]])
+                    o.boundary_list = mm_np[b]
                     o.norm_value = np.sqrt(ss[b * L])
         return objs
 

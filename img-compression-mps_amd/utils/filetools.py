@@ -59,9 +59,12 @@ def minmax_many(tensors, with_sumsq=False):
 
     lib = _lib.load()
     ts = []
-    for t in tensors:
-        u = _f32(t)
-        ts.append(u if u.is_contiguous() else u.contiguous())
+    for t in tensors:  # fp32 contiguous tensors (the usual case) pass through without a call
+        if t.dtype is torch.float32 and t.is_contiguous():
+            ts.append(t)
+        else:
+            u = _f32(t)
+            ts.append(u if u.is_contiguous() else u.contiguous())
     count = len(ts)
     if count == 0:
         return ([], []) if with_sumsq else []
