@@ -182,8 +182,10 @@ def main():
     last = {}
 
     def step():
+        # wait=False: the step returns when everything is enqueued; the next step queues behind it on the same
+        # streams (like the steps of a training loop) and the barrier of the timed region synchronises the device
         objs, recs = batch_mod.encode_decode_concurrent(xs, groups=job["groups"], mode=job["mode"],
-                                                         max_bond=job["chi"], pool=pool)
+                                                         max_bond=job["chi"], pool=pool, wait=False)
         last["obj"], last["rec"] = objs[0], recs[0]
 
     def group_step(n):  # one lockstep group of n volumes on the current stream

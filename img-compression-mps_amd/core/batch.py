@@ -71,14 +71,18 @@ def group_streams(n: int):
 
 
 def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str = "Std", norm: bool = False,
-                             max_bond=None, cutoff: float = 1e-10, reconstruct: bool = True, pool=None):
+                             max_bond=None, cutoff: float = 1e-10, reconstruct: bool = True, pool=None,
+                             wait: bool = True):
     """Throughput path for a list of same-shape device volumes: the list is cut into ``groups``
     contiguous groups; every group runs on its own host thread and HIP stream and encodes its
     volumes in lockstep (``NDMPS.from_tensors``).  The eigen-solver phases of a group keep only a
     fraction of the chip busy, so several groups in flight overlap them with each other's
     streaming phases (measured on MI355X: 8 volumes in flight 3.1, 16 -> 4.5, 32 -> 5.3 Gvoxel/s).
     Returns (list of NDMPS, list of reconstructions or None) in input order; every group's work has
-    completed on the device when the call returns."""
+    completed on the device when the call returns -- unless ``wait=False``: then the reconstructions are
+    still being written on the groups' streams when the call returns (the NDMPS objects are complete) and the
+    caller synchronises the device before reading them; a following call queues behind them on the same
+    streams, so consecutive batches run back to back without the host in between."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
 
@@ -104,7 +108,8 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
             recs = NDMPS.to_tensors(objs, as_torch=True) if reconstruct else None
         # host-side completion: a device-side wait on the caller's stream would sit in whichever
         # hardware queue that stream shares with a group and hold that group's next launches behind it
-        stream.synchronize()
+        if wait:
+            stream.synchronize()
         return objs, recs
 
     if pool is None:
