@@ -103,9 +103,12 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
         stream = streams[slot]
         with torch.cuda.stream(stream):
             stream.wait_event(ready)  # inputs produced on the caller's stream
-            objs = NDMPS.from_tensors([tensor_list[i] for i in idx], norm=norm, mode=mode, max_bond=max_bond,
-                                      cutoff=cutoff)
-            recs = NDMPS.to_tensors(objs, as_torch=True) if reconstruct else None
+            if reconstruct:
+                objs, recs = NDMPS.from_tensors([tensor_list[i] for i in idx], norm=norm, mode=mode, max_bond=max_bond,
+                                                cutoff=cutoff, reconstruct=True)
+            else:
+                objs, recs = NDMPS.from_tensors([tensor_list[i] for i in idx], norm=norm, mode=mode,
+                                                max_bond=max_bond, cutoff=cutoff), None
         # host-side completion: a device-side wait on the caller's stream would sit in whichever
         # hardware queue that stream shares with a group and hold that group's next launches behind it
         if wait:

@@ -238,7 +238,7 @@ class NDMPS:
 
     @classmethod
     def from_tensors(cls, tensors, norm: bool = False, mode: str = "Std", max_bond=None,
-                     cutoff: float = 1e-10, device=None, dtype=None):
+                     cutoff: float = 1e-10, device=None, dtype=None, reconstruct: bool = False):
         """
         Encode a list of independent tensors OF THE SAME SHAPE in one batched pass (what the
         reference does with a Python loop, evaluation/benchmark.py:73-76).  The volumes go through
@@ -252,13 +252,18 @@ class NDMPS:
         run on the bf16 MFMA with fp32 accumulation, Gram matrices and eigen-decompositions stay fp64.
         ``to_tensor`` then contracts in bf16 as well.  Results carry bf16 rounding (2^-9 relative per
         stored value).
+
+        ``reconstruct=True`` returns ``(objects, reconstructions)``: the chain products of the whole list are issued
+        as soon as the sweep has returned, BEFORE the Python objects are built (their construction then runs
+        under the decode instead of in front of it); the reconstructions (device tensors) equal
+        ``NDMPS.to_tensors(objects, as_torch=True)``.
         """
         torch = _torch()
         _lib.require_device()
         lib = _lib.load()
         tensors = list(tensors)
         if not tensors:
-            return []
+            return ([], []) if reconstruct else []
         first = tensors[0]
         if device is None:
             device = first.device if isinstance(first, torch.Tensor) and first.is_cuda else "cuda"
@@ -369,6 +374,39 @@ class NDMPS:
             caps = np.array([int(max_bonds[i]) for i in range(L + 1)], dtype=np.int64)
             offs = [int(core_off[i]) for i in range(L + 1)]
             spec_offs = [int(spec_off[i]) for i in range(L + 1)]
+            recs = None
+            n_tail = int(lib.ndmps_chain_tail_columns(L, cdims)) if (reconstruct and not bf16 and batch > 1) else 0
+            if n_tail > 0 and not os.environ.get("NDMPS_NO_FUSED_DECODE"):
+                # decode straight from the arena: padded cores are valid cores of the cap bonds (zeros beyond the rank)
+                dec_bonds = (C.c_int64 * (batch * (L + 1)))()
+                dec_cores = (C.c_void_p * (batch * L))()
+                for b in range(batch):
+                    dec_bonds[b * (L + 1): (b + 1) * (L + 1)] = [int(v) for v in (caps if padded else bonds_np[b])]
+                    row = arena_base + b * arena_step
+                    for i in range(L):
+                        dec_cores[b * L + i] = row + offs[i] * esize
+                r_off, c_off, c_perm = plan.split_tables(n_tail, device)
+                out = torch.empty((batch,) + shape, dtype=torch.float32, device=device)
+                cws_bytes = int(lib.ndmps_chain_batched_workspace_bytes(batch, L, cdims, dec_bonds))
+                cws = torch.empty(cws_bytes, dtype=torch.uint8, device=device)
+                obase, ostep = out.data_ptr(), numel * 4
+                outs = (C.c_void_p * batch)(*[obase + b * ostep for b in range(batch)])
+                with _span("chain"):
+                    _lib.check(lib.ndmps_chain_contract_scatter_batched_f32(
+                        batch, L, cdims, dec_bonds, dec_cores, outs, r_off.data_ptr(), c_off.data_ptr(), c_perm.data_ptr(),
+                        n_tail, cws.data_ptr(), cws_bytes, stream))
+                recs = list(out.unbind(0))
+                if mode == "DCT":
+                    n_last = shape[-1]
+                    basis = _dct_basis(n_last, device)
+                    done = []
+                    for r in recs:
+                        rec = torch.empty_like(r)
+                        _lib.check(lib.ndmps_idct_last_f32(r.data_ptr(), rec.data_ptr(), numel // n_last, n_last,
+                                                           basis.data_ptr(), stream))
+                        done.append(rec)
+                    recs = done
+                del cws
             per_site = None
             if padded and bool((bonds_np == caps).all()):
                 # every cap binds: the padded cores ARE the cores; L narrow / view / unbind calls serve the whole
@@ -420,6 +458,8 @@ class NDMPS:
                 for b, o in enumerate(objs):
                     o.boundary_list = mm_np[b]
                     o.norm_value = np.sqrt(ss[b * L])
+        if reconstruct:
+            return objs, (recs if recs is not None else cls.to_tensors(objs, as_torch=True))
         return objs
 
     # ----------------------------------------------------------------- bookkeeping

@@ -814,6 +814,11 @@ def test_to_tensors_equals_to_tensor_per_object(shape, chi, mode, count):
     as_numpy = NDMPS.to_tensors(objs)
     assert all(isinstance(r, np.ndarray) and np.array_equal(r, a.cpu().numpy()) for r, a in zip(as_numpy, one_by_one))
     assert NDMPS.to_tensors([]) == []
+    # reconstruct=True: the decode is issued before the objects exist; same result
+    objs2, recs2 = NDMPS.from_tensors(vols, mode=mode, max_bond=chi, reconstruct=True)
+    for o, r in zip(objs2, recs2):
+        assert torch.equal(r, o.to_tensor(as_torch=True))
+    assert NDMPS.from_tensors([], reconstruct=True) == ([], [])
     assert torch.equal(NDMPS.to_tensors(objs[:1], as_torch=True)[0], one_by_one[0])
 
 
