@@ -277,6 +277,32 @@ gemm_body(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
   }
 
   // ---- epilogue
+  if (IDX && ix.c_row) {
+    // table-addressed C: every offset this lane needs is requested first (TM * NACC row offsets, TN column offsets),
+    // then the stores go out -- one dependent table load in front of every store made the epilogue a chain of
+    // L2 round trips (the last chain product wrote the volume at 1 TB/s)
+    int64_t roff[TM][MF::NACC], coff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + (wn * TN + j) * MT + MF::acc_col(lane);
+      coff[j] = col < N ? ix.c_col[col] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < MF::NACC; ++r) {
+        const int64_t row = m0 + (wm * TM + i) * MT + MF::acc_row(r, lane);
+        roff[i][r] = row < M ? ix.c_row[row] : -1;
+      }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < MF::NACC; ++r)
+          if (roff[i][r] >= 0 && coff[j] >= 0) C[roff[i][r] + coff[j]] = acc[i][j][r];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -285,10 +311,7 @@ gemm_body(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
 #pragma unroll
       for (int r = 0; r < MF::NACC; ++r) {
         const int64_t row = m0 + (wm * TM + i) * MT + MF::acc_row(r, lane);
-        if (row < M && col < N) {
-          if (IDX && ix.c_row) C[ix.c_row[row] + ix.c_col[col]] = acc[i][j][r];
-          else C[row * ldc + col] = acc[i][j][r];
-        }
+        if (row < M && col < N) C[row * ldc + col] = acc[i][j][r];
       }
     }
 }
