@@ -277,6 +277,60 @@ gemm_body(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
   }
 
   // ---- epilogue
+  if constexpr (IDX && MF::MT == 32 && BM == 128 && BN == 128 && sizeof(T) == 4) {
+    if (ix.c_row) {
+      // table-addressed C of the big tile (the last chain product: the reconstructed volume, written once): every
+      // 32 x 32 accumulator tile goes through a wave-private LDS patch so that a lane owns FOUR consecutive columns
+      // of a row -- 16-byte stores wherever the four column offsets are consecutive (64-byte runs at 256^3)
+      // instead of 4-byte ones.  All offsets are requested before the first store.
+      __shared__ float cstage[4][32][36];
+      float (*st)[36] = cstage[wave];
+      const int rl0 = lane >> 3, cl = (lane & 7) * 4;
+      int64_t roff[TM][4], coff[TN][4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int64_t col = n0 + (wn * TN + j) * MT + cl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) coff[j][e] = col + e < N ? ix.c_col[col + e] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int64_t row = m0 + (wm * TM + i) * MT + rl0 + 8 * ps;
+          roff[i][ps] = row < M ? ix.c_row[row] : -1;
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+          for (int r = 0; r < MF::NACC; ++r) st[MF::acc_row(r, lane)][MF::acc_col(lane)] = acc[i][j][r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const bool run = coff[j][0] >= 0 && coff[j][3] == coff[j][0] + 3 && coff[j][1] == coff[j][0] + 1 &&
+                           coff[j][2] == coff[j][0] + 2;
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const float4 v = *reinterpret_cast<const float4*>(&st[rl0 + 8 * ps][cl]);
+            const int64_t ro = roff[i][ps];
+            if (ro < 0) continue;
+            if (run && ((ro + coff[j][0]) & 3) == 0) {
+              *reinterpret_cast<float4*>(C + ro + coff[j][0]) = v;
+            } else {
+              if (coff[j][0] >= 0) C[ro + coff[j][0]] = v.x;
+              if (coff[j][1] >= 0) C[ro + coff[j][1]] = v.y;
+              if (coff[j][2] >= 0) C[ro + coff[j][2]] = v.z;
+              if (coff[j][3] >= 0) C[ro + coff[j][3]] = v.w;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next tile
+        }
+      return;
+    }
+  }
   if (IDX && ix.c_row) {
     // table-addressed C: every offset this lane needs is requested first (TM * NACC row offsets, TN column offsets),
     // then the stores go out -- one dependent table load in front of every store made the epilogue a chain of
