@@ -181,6 +181,62 @@ def test_gram_fp64(m, n):
     assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("batch,m,n,k,ta,tb", [(3, 33, 17, 65, 0, 0), (5, 200, 64, 136, 0, 1), (2, 64, 512, 64, 1, 0),
+                                               (7, 1000, 8, 8, 0, 0), (4, 130, 129, 131, 1, 1), (64, 16, 16, 16, 0, 1)])
+def test_gemm_batched_equals_gemm_per_triple(batch, m, n, k, ta, tb):
+    """ndmps_sgemm_batched / ndmps_dgemm_batched run the same tiles on operand triples taken from the kernel
+    arguments: bit-identical to one ndmps_sgemm / ndmps_dgemm call per triple, and correct against NumPy."""
+    lib = _lib.load()
+    assert lib.ndmps_gemm_batched_max() >= 64
+    rng = np.random.default_rng(batch * 7 + m)
+    for dt, one, many, tol in ((torch.float32, lib.ndmps_sgemm, lib.ndmps_sgemm_batched, 4e-7),
+                               (torch.float64, lib.ndmps_dgemm, lib.ndmps_dgemm_batched, 1e-14)):
+        a = [dev(rng.standard_normal((k, m) if ta else (m, k)), dt) for _ in range(batch)]
+        b = [dev(rng.standard_normal((n, k) if tb else (k, n)), dt) for _ in range(batch)]
+        c1 = [torch.full((m, n), float("nan"), dtype=dt, device=DEV) for _ in range(batch)]
+        c2 = [torch.full((m, n), float("nan"), dtype=dt, device=DEV) for _ in range(batch)]
+        for x, y, z in zip(a, b, c1):
+            _lib.check(one(ta, tb, m, n, k, x.data_ptr(), x.shape[1], y.data_ptr(), y.shape[1], z.data_ptr(), n, sp()))
+        pa = (C.c_void_p * batch)(*[x.data_ptr() for x in a])
+        pb = (C.c_void_p * batch)(*[x.data_ptr() for x in b])
+        pc = (C.c_void_p * batch)(*[x.data_ptr() for x in c2])
+        _lib.check(many(batch, ta, tb, m, n, k, pa, a[0].shape[1], pb, b[0].shape[1], pc, n, sp()))
+        for x, y, z1, z2 in zip(a, b, c1, c2):
+            assert torch.equal(z1, z2)
+            x64, y64 = x.double().cpu().numpy(), y.double().cpu().numpy()
+            ref = (x64.T if ta else x64) @ (y64.T if tb else y64)
+            scale = np.abs(x64).sum(axis=0 if ta else 1).max() * np.abs(y64).max() + 1e-30
+            assert np.abs(z2.double().cpu().numpy() - ref).max() <= tol * scale * max(1, k ** 0.5)
+    with pytest.raises(ValueError):
+        _lib.check(lib.ndmps_sgemm_batched(65, 0, 0, 1, 1, 1, pa, 1, pb, 1, pc, 1, sp()))
+
+
+@pytest.mark.parametrize("batch,m,n", [(1, 4096, 512), (3, 1000, 200), (5, 300, 128), (32, 512, 512), (2, 20000, 384),
+                                       (4, 257, 131)])
+def test_gram_batched_fp64(batch, m, n):
+    """One launch for the Gram matrices of a group (n >= 128): exactly symmetric, fp64-accurate, and reproducible
+    (a second call gives the same bits)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(batch + m + n)
+    mats = [dev(rng.standard_normal((m, n)).astype(np.float32), torch.float32) for _ in range(batch)]
+    g = torch.full((batch, n, n), float("nan"), dtype=torch.float64, device=DEV)
+    nbytes = lib.ndmps_gram_batched_workspace_bytes(batch, m, n)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    ptrs = (C.c_void_p * batch)(*[x.data_ptr() for x in mats])
+    _lib.check(lib.ndmps_gram_batched_f32(batch, ptrs, m, n, n, g.data_ptr(), n * n, ws.data_ptr(), nbytes, sp()))
+    first = g.clone()
+    _lib.check(lib.ndmps_gram_batched_f32(batch, ptrs, m, n, n, g.data_ptr(), n * n, ws.data_ptr(), nbytes, sp()))
+    assert torch.equal(first, g)
+    for b in range(batch):
+        a64 = mats[b].double().cpu().numpy()
+        ref = a64.T @ a64
+        got = g[b].cpu().numpy()
+        assert np.array_equal(got, got.T)
+        assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    assert lib.ndmps_gram_batched_workspace_bytes(batch, m, 64) == 0  # narrower matrices: ndmps_gram_f32 per matrix
+
+
 def _syevj(lib, g):
     n = g.shape[0]
     tg = dev(g)
