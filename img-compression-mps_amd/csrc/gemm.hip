@@ -832,6 +832,24 @@ gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __re
 
   // staging map: GW_KB rows x 32 float4 per panel, 4 per thread
   float4 pi[4], pj[4];
+  // gathered reads: the two column offsets of this thread never change (its column quad is fixed) and the row
+  // offsets of a chunk are requested one chunk ahead -- looked up inside fetch() they put a table round trip in
+  // front of the data loads, and the wave sat through it before it could start the chunk's MFMAs (+18 %)
+  int64_t coli = 0, colj = 0, ro[4] = {0, 0, 0, 0};
+  auto row_offsets = [&](int64_t r0) {
+    if (row_off) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int64_t row = r0 + (tid + 256 * v) / 32;
+        ro[v] = row < r_end ? row_off[row] : 0;
+      }
+    }
+  };
+  if (row_off) {
+    const int c4 = (tid % 32) * 4;
+    if (i0 + c4 + 3 < n) coli = col_off[i0 + c4];
+    if (j0 + c4 + 3 < n) colj = col_off[j0 + c4];
+  }
   auto fetch = [&](int64_t r0) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -840,9 +858,9 @@ gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __re
       const int64_t row = r0 + rr;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
       if (row < r_end && row_off) {  // gathered: offsets additive in (row, column); vec_ok guaranteed by the host
-        const TIN* base = A + row_off[row];
-        if (i0 + c4 + 3 < n) x = load4_as_f32(base + col_off[i0 + c4]);
-        if (!diag && j0 + c4 + 3 < n) y = load4_as_f32(base + col_off[j0 + c4]);
+        const TIN* base = A + ro[v];
+        if (i0 + c4 + 3 < n) x = load4_as_f32(base + coli);
+        if (!diag && j0 + c4 + 3 < n) y = load4_as_f32(base + colj);
       } else if (row < r_end) {
         const TIN* base = A + row * lda;
         if (vec_ok && i0 + c4 + 3 < n) x = load4_as_f32(base + i0 + c4);
@@ -902,14 +920,19 @@ gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __re
 #pragma unroll
     for (int a = 0; a < 16; ++a) acc[a] = (f64x4){0.0, 0.0, 0.0, 0.0};
     if (r_begin < r_end) {
+      row_offsets(r_begin);
       fetch(r_begin);
       stash(0);
+      row_offsets(r_begin + GW_KB);
     }
     __syncthreads();
     int buf = 0;
     for (int64_t r0 = r_begin; r0 < r_end; r0 += GW_KB, buf ^= 1) {
       const bool more = r0 + GW_KB < r_end;
-      if (more) fetch(r0 + GW_KB);  // in flight under the MFMAs
+      if (more) {
+        fetch(r0 + GW_KB);          // in flight under the MFMAs
+        row_offsets(r0 + 2 * GW_KB);  // for the fetch of the next iteration
+      }
       const float* Pi = g128_lds + (2 * buf) * G128_PANEL + lr * G128_LD + lc;
       const float* Pj = ROLE == 0 ? Pi + G128_PANEL : Pi;
       gram128_chunk<ROLE>(Pi + a_col, Pj + b_col, acc);

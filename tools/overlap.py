@@ -16,10 +16,10 @@ def main():
     con = sqlite3.connect(sys.argv[1])
     rows = con.execute("select name, start, end, queue_id from kernels order by start").fetchall()
     qs = collections.Counter(r[3] for r in rows)
-    work = [q for q, c in qs.items() if c > 2000]  # the group streams (the default stream generates the volumes)
+    work = [q for q, c in qs.items() if c > 300]  # the group streams (the default stream generates the volumes)
     rows = [r for r in rows if r[3] in work and "at::native" not in r[0]]
     t0 = rows[0][1]
-    team = [r for r in rows if "gram_wide" in r[0]]
+    team = [r for r in rows if "gram128" in r[0] or "gram_wide" in r[0]]
     if team and len(sys.argv) <= 3:  # default window: from the first big Gram launch (volume generation precedes it)
         rows = [r for r in rows if r[1] >= team[0][1]]
     lo = float(sys.argv[2]) * 1e6 + t0 if len(sys.argv) > 3 else rows[0][1]
