@@ -68,4 +68,9 @@ constexpr int kSpanGram = 3;  // `bytes` of the span = flops
 void* span_begin(hipStream_t s);
 void span_end(void* begin, hipStream_t s, int slot, int64_t launches, int64_t bytes);
 
+// turns between streams for kernels that fill the GPU alone (util.hip)
+constexpr int kTurnTeam = 0, kTurnGram = 1;
+int turn_begin(hipStream_t s, int which);
+int turn_end(hipStream_t s, int which);
+
 }  // namespace ndmps

@@ -1707,43 +1707,13 @@ int team_slots(int& slots) {
   return NDMPS_OK;
 }
 
-// At most one team kernel in flight per device (see trd_team_kernel).  The turn is taken ON THE DEVICE: a one-thread
-// kernel in front of the team kernel spins on a lock word until it owns it, a one-thread kernel behind it gives it
-// back.  The spinner holds one wave slot and a handful of registers, so the owner's kernels always fit beside it,
-// and whichever stream reaches its team kernel first runs first.  (An event chain follows the order in which the
-// HOST enqueues: a host thread far ahead of its stream queued its later sites in front of the other stream's earlier
-// one and that stream sat idle for 6.7 ms of a 41 ms step; synchronising the host with its stream before the
-// launch cost more than it gained.)  The spin is bounded like every wait of the team kernel: after 3 s the turn
-// is taken regardless.
-__global__ void team_acquire_kernel(unsigned* __restrict__ lock) {
-  const long long t0 = wall_clock64();
-  while (atomicCAS(lock, 0u, 1u) != 0u) {
-    if (wall_clock64() - t0 > kTeamSpinTicks) break;
-    __builtin_amdgcn_s_sleep(8);
-  }
-}
-__global__ void team_release_kernel(unsigned* __restrict__ lock) { atomicExch(lock, 0u); }
-
+// At most one team kernel in flight per device (see trd_team_kernel); the turn is taken on the device
+// (ndmps::turn_begin / turn_end, util.hip).
 template <typename F>
 int team_launch(hipStream_t s, F&& launch) {
-  static std::mutex mu;
-  static unsigned* lock_word[64] = {};
-  int dev = 0;
-  NDMPS_CHECK_HIP(hipGetDevice(&dev));
-  NDMPS_REQUIRE(dev >= 0 && dev < 64, "device index %d outside [0, 64)", dev);
-  unsigned* word = nullptr;
-  {
-    std::lock_guard<std::mutex> guard(mu);
-    if (!lock_word[dev]) {  // 256 bytes per device, once: the only allocation of the solver
-      NDMPS_CHECK_HIP(hipMalloc((void**)&lock_word[dev], 256));
-      NDMPS_CHECK_HIP(hipMemset(lock_word[dev], 0, 256));
-    }
-    word = lock_word[dev];
-  }
-  hipLaunchKernelGGL(team_acquire_kernel, dim3(1), dim3(1), 0, s, word);
+  NDMPS_TRY(ndmps::turn_begin(s, ndmps::kTurnTeam));
   launch();
-  hipLaunchKernelGGL(team_release_kernel, dim3(1), dim3(1), 0, s, word);
-  NDMPS_LAUNCH_CHECK();
+  NDMPS_TRY(ndmps::turn_end(s, ndmps::kTurnTeam));
   return NDMPS_OK;
 }
 

@@ -14,6 +14,8 @@
 // B[k=l>>5][j=l&31]; for the f64 16x16x4 MFMA A[i=l&15][k=l>>4], B[k=l>>4][j=l&15].  Both
 // operand tiles are therefore staged k-major in LDS (As[k][m], Bs[k][n]) so a fragment
 // read is 32 (16) consecutive words per half (quarter) wave: conflict-free ds_read.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include <mutex>
@@ -1324,6 +1326,10 @@ int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int6
   if (d_row_off)
     NDMPS_REQUIRE(d_col_off && vec_ok, "gathered Gram needs n %% 4 == 0 and aligned bases");
   double* partial = (double*)d_ws;
+  // a launch that fills the GPU for milliseconds (a lockstep group's raw Gram) takes its turn with those of other
+  // streams: two of them at once gain nothing (both MFMA-bound) and keep each other's groups in phase
+  const bool turn = (int64_t)batch * g.slots >= 4096 && !getenv("NDMPS_GRAM_NO_TURN");
+  if (turn) NDMPS_TRY(ndmps::turn_begin(s, ndmps::kTurnGram));
   void* span = ndmps::span_begin(s);
   for (int base = 0; base < batch; base += kGram128MaxBatch) {
     const int count = std::min(kGram128MaxBatch, batch - base);
@@ -1334,6 +1340,7 @@ int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int6
   }
   // algorithmic work of the span: the upper triangle incl. the diagonal, 2 flops per product
   ndmps::span_end(span, s, ndmps::kSpanGram, (batch + kGram128MaxBatch - 1) / kGram128MaxBatch, (int64_t)batch * m * n * (n + 1));
+  if (turn) NDMPS_TRY(ndmps::turn_end(s, ndmps::kTurnGram));
   hipLaunchKernelGGL(gram128_reduce_kernel, dim3(g.n_off + g.n_diag, 64, batch), dim3(256), 0, s, partial, g, d_G, stride_G, n);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;

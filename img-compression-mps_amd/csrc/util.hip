@@ -183,3 +183,54 @@ extern "C" int ndmps_profile_collect(int slot, double* h_ms, int64_t* h_launches
   *h_bytes = bytes;
   return NDMPS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- device-side turns
+// Kernels that fill the GPU alone (the register-resident tridiagonalisation, the big Gram launches) take turns
+// between streams ON THE DEVICE: a one-thread kernel in front spins on a lock word until it owns it, a one-thread
+// kernel behind gives it back.  The spinner holds one wave slot and a handful of registers, so the owner's kernels
+// always fit beside it, and whichever stream gets there first runs first (an event chain would follow the order in
+// which the HOST enqueues).  Bounded like every wait here: after 3 s the turn is taken regardless.
+namespace {
+constexpr long long kTurnSpinTicks = 300000000LL;  // 3 s of the 100 MHz wall clock
+__global__ void turn_acquire_kernel(unsigned* __restrict__ lock) {
+  const long long t0 = wall_clock64();
+  while (atomicCAS(lock, 0u, 1u) != 0u) {
+    if (wall_clock64() - t0 > kTurnSpinTicks) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+__global__ void turn_release_kernel(unsigned* __restrict__ lock) { atomicExch(lock, 0u); }
+
+int turn_word(int which, unsigned** word) {
+  static std::mutex mu;
+  static unsigned* base[64] = {};
+  int dev = 0;
+  NDMPS_CHECK_HIP(hipGetDevice(&dev));
+  NDMPS_REQUIRE(dev >= 0 && dev < 64 && which >= 0 && which < 4, "device index %d outside [0, 64)", dev);
+  std::lock_guard<std::mutex> guard(mu);
+  if (!base[dev]) {  // 256 bytes per device, once: the only allocation outside ndmps_plan_create
+    NDMPS_CHECK_HIP(hipMalloc((void**)&base[dev], 256));
+    NDMPS_CHECK_HIP(hipMemset(base[dev], 0, 256));
+  }
+  *word = base[dev] + 16 * which;  // 64 bytes apart
+  return NDMPS_OK;
+}
+}  // namespace
+
+namespace ndmps {
+int turn_begin(hipStream_t s, int which) {
+  unsigned* word = nullptr;
+  NDMPS_TRY(turn_word(which, &word));
+  hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(1), 0, s, word);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+int turn_end(hipStream_t s, int which) {
+  unsigned* word = nullptr;
+  NDMPS_TRY(turn_word(which, &word));
+  hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(1), 0, s, word);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+}  // namespace ndmps
+
