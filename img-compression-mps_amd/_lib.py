@@ -43,6 +43,9 @@ SIGNATURES = {
     "ndmps_sumsq_f32": (C.c_int, [vp, i64, p_f64, vp, i64, vp]),
     "ndmps_minmax_f32": (C.c_int, [vp, i64, p_f32, p_f32, vp, i64, vp]),
     "ndmps_minmax_many_workspace_bytes": (i64, [C.c_int]),
+    "ndmps_minmax_partials_bytes": (i64, [C.c_int]),
+    "ndmps_minmax_arena_launch_f32": (C.c_int, [vp, i64, C.c_int, C.c_int, p_i64, p_i64, vp, vp]),
+    "ndmps_minmax_collect": (C.c_int, [C.c_int, vp, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]),
     "ndmps_minmax_many_f32": (C.c_int, [C.c_int, C.POINTER(vp), p_i64, p_f32, p_f64, vp, i64, vp]),
     "ndmps_scale_f32": (C.c_int, [vp, i64, C.c_double, vp]),
     "ndmps_reduce_workspace_bytes": (i64, []),

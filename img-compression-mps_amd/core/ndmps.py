@@ -171,6 +171,44 @@ def _dct_basis(n, device):
         return _DCT_CACHE[key]
 
 
+class _GroupState:
+    """min / max of every core and the norm of every volume of a lockstep group, ISSUED with the sweep (one
+    launch over the group's arena) and COLLECTED when the first object is asked for boundary_list / norm_value:
+    the reference computes them inside from_tensor (ndmps.py:75-76); here nothing on the device is skipped, only
+    the copy back to the host waits until somebody wants the numbers."""
+
+    def __init__(self, objs, partial, count, n_cores, stream):
+        import weakref
+
+        self.refs = [weakref.ref(o) for o in objs]
+        self.partial, self.count, self.n_cores, self.stream = partial, count, n_cores, stream
+        self.done = False
+
+    def resolve(self):
+        if self.done:
+            return
+        self.done = True
+        lib = _lib.load()
+        out = (C.c_float * (2 * self.count))()
+        ss = (C.c_double * self.count)()
+        _lib.check(lib.ndmps_minmax_collect(self.count, self.partial.data_ptr(), out, ss, self.stream))
+        mm = np.frombuffer(out, dtype=np.float32).astype(np.float64).reshape(-1, self.n_cores, 2)
+        ssn = np.frombuffer(ss, dtype=np.float64)
+        for b, ref in enumerate(self.refs):
+            o = ref()
+            if o is None or o.__dict__.get("_state_group") is not self:
+                continue
+            d = o.__dict__
+            d["_state_group"] = None
+            # attributes set explicitly in the meantime (update_*, compress, a caller) win
+            if not d.pop("_boundary_set", False):
+                d["_boundary_list"] = mm[b].copy()
+            if not d.pop("_norm_set", False):
+                # sites 1..L-1 are right-isometric after the sweep: mps @ mps = ||site 0||_F^2 (~1e-7 relative)
+                d["_norm_value"] = np.sqrt(ssn[b * self.n_cores])
+        self.partial = None
+
+
 class NDMPS:
     """
     Class for storing and compressing N-dimensional tensors using MPS (device resident).
@@ -189,6 +227,47 @@ class NDMPS:
         # tensor shape: known from the map when one is handed in (the reference's constructor allows
         # that, ndmps.py:17-35), set by from_tensors / codec.loads otherwise
         self._shape = tuple(int(v) for v in np.shape(encoding_map)[:-1]) if encoding_map is not None else None
+
+    # boundary_list / norm_value: plain attributes as in the reference; after from_tensors their device-side
+    # reductions are in flight and the values arrive on first access (_GroupState)
+    def _resolve_state(self):
+        g = self.__dict__.get("_state_group")
+        if g is not None:
+            g.resolve()
+
+    @property
+    def boundary_list(self):
+        self._resolve_state()
+        return self.__dict__.get("_boundary_list")
+
+    @boundary_list.setter
+    def boundary_list(self, value):
+        self.__dict__["_boundary_list"] = value
+        if self.__dict__.get("_state_group") is not None:
+            self.__dict__["_boundary_set"] = True
+
+    @property
+    def norm_value(self):
+        self._resolve_state()
+        return self.__dict__.get("_norm_value")
+
+    @norm_value.setter
+    def norm_value(self, value):
+        self.__dict__["_norm_value"] = value
+        if self.__dict__.get("_state_group") is not None:
+            self.__dict__["_norm_set"] = True
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        self._resolve_state()
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_spectra_lazy" and v is not None:
+                v = (v[0].copy(), v[1], v[2])
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     # singular values kept by the sweep, per bond (None for site 0); from_tensors stores them lazily
     @property
@@ -452,12 +531,23 @@ class NDMPS:
                 # launch.  The sweep leaves sites 1..L-1 right-isometric (rows of V^T), so
                 # mps @ mps = ||site 0||_F^2 up to the fp32 rounding of those rows (~1e-7 relative);
                 # update_norm() evaluates the full overlap contraction like the reference.
-                all_cores = [c for o in objs for c in o.mps.cores]
-                mm, ss = _ft.minmax_many(all_cores, with_sumsq=True)
-                mm_np = np.asarray(mm, dtype=np.float64).reshape(batch, L, 2)
-                for b, o in enumerate(objs):
-                    o.boundary_list = mm_np[b]
-                    o.norm_value = np.sqrt(ss[b * L])
+                if per_site is not None and not bf16 and L <= 64 and batch * L <= 65535:
+                    # cores = cap-shaped views of the arena: one launch now, the numbers on first access
+                    count = batch * L
+                    partial = torch.empty(int(lib.ndmps_minmax_partials_bytes(count)) // 8, dtype=torch.float64, device=device)
+                    lens = _lib.i64_array([int(caps[i]) * dims[i] * int(caps[i + 1]) for i in range(L)])
+                    _lib.check(lib.ndmps_minmax_arena_launch_f32(arena_base, core_total, batch, L, _lib.i64_array(offs[:L]),
+                                                                 lens, partial.data_ptr(), stream))
+                    group = _GroupState(objs, partial, count, L, stream)
+                    for o in objs:
+                        o.__dict__["_state_group"] = group
+                else:
+                    all_cores = [c for o in objs for c in o.mps.cores]
+                    mm, ss = _ft.minmax_many(all_cores, with_sumsq=True)
+                    mm_np = np.asarray(mm, dtype=np.float64).reshape(batch, L, 2)
+                    for b, o in enumerate(objs):
+                        o.boundary_list = mm_np[b]
+                        o.norm_value = np.sqrt(ss[b * L])
         if reconstruct:
             return objs, (recs if recs is not None else cls.to_tensors(objs, as_torch=True))
         return objs

@@ -272,6 +272,96 @@ extern "C" int ndmps_minmax_many_f32(int count, const float* const* h_ptrs, cons
   return NDMPS_OK;
 }
 
+// ---- the same reduction for the cores of a lockstep group that sit in one arena (row b = volume b, core i at
+//      offsets[i], lens[i] elements), split in two so that nothing waits in between: _launch enqueues the kernel
+//      (asynchronous; tensor (b, i) -> entry b * n_cores + i of the partial buffer), _collect brings the partials
+//      back and folds them (synchronises).  Lets a caller issue the reductions with the sweep and read
+//      boundary_list / norm (core/ndmps.py:75-76) when somebody asks for them.
+namespace {
+constexpr int kArenaCores = 64;
+struct ArenaCores {
+  int64_t offset[kArenaCores];
+  int64_t len[kArenaCores];
+};
+__global__ void __launch_bounds__(256)
+minmax_arena_kernel(const float* __restrict__ base, int64_t row_stride, int n_cores, ArenaCores ac,
+                    double* __restrict__ partial) {
+  __shared__ float rmin[4], rmax[4];
+  __shared__ double rsum[4];
+  const int t = blockIdx.y;  // tensor index = volume * n_cores + core
+  const float* x = base + (int64_t)(t / n_cores) * row_stride + ac.offset[t % n_cores];
+  const int64_t n = ac.len[t % n_cores];
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  double ss = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float v = x[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+    ss += (double)v * (double)v;
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) {
+    rmin[threadIdx.x >> 6] = lo;
+    rmax[threadIdx.x >> 6] = hi;
+    rsum[threadIdx.x >> 6] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = partial + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = (double)fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3]));
+    o[1] = (double)fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+    o[2] = (rsum[0] + rsum[1]) + (rsum[2] + rsum[3]);
+  }
+}
+}  // namespace
+
+extern "C" int64_t ndmps_minmax_partials_bytes(int count) {
+  return count > 0 ? (int64_t)count * kManySlices * 3 * 8 : 0;
+}
+
+extern "C" int ndmps_minmax_arena_launch_f32(const float* d_base, int64_t row_stride, int batch, int n_cores,
+                                             const int64_t* h_offsets, const int64_t* h_lens, double* d_partial,
+                                             ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_base && d_partial && h_offsets && h_lens && batch >= 1 && n_cores >= 1 && n_cores <= kArenaCores &&
+                    (int64_t)batch * n_cores <= 65535,
+                "bad minmax_arena argument (batch=%d cores=%d)", batch, n_cores);
+  ArenaCores ac;
+  for (int i = 0; i < n_cores; ++i) {
+    NDMPS_REQUIRE(h_offsets[i] >= 0 && h_lens[i] > 0 && h_offsets[i] + h_lens[i] <= row_stride, "core %d leaves its arena row", i);
+    ac.offset[i] = h_offsets[i];
+    ac.len[i] = h_lens[i];
+  }
+  hipLaunchKernelGGL(minmax_arena_kernel, dim3(kManySlices, batch * n_cores), dim3(256), 0, (hipStream_t)stream, d_base,
+                     row_stride, n_cores, ac, d_partial);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_minmax_collect(int count, const double* d_partial, float* h_out, double* h_sumsq,
+                                    ndmps_stream_t stream) {
+  NDMPS_REQUIRE(count >= 1 && d_partial && h_out, "bad minmax_collect argument");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<double> host((size_t)count * kManySlices * 3);
+  NDMPS_CHECK_HIP(hipMemcpyAsync(host.data(), d_partial, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < count; ++i) {
+    double lo = FLT_MAX, hi = -FLT_MAX, ss = 0.0;
+    for (int j = 0; j < kManySlices; ++j) {
+      const double* o = &host[3 * ((size_t)i * kManySlices + j)];
+      lo = std::min(lo, o[0]);
+      hi = std::max(hi, o[1]);
+      ss += o[2];
+    }
+    h_out[2 * i] = (float)lo;
+    h_out[2 * i + 1] = (float)hi;
+    if (h_sumsq) h_sumsq[i] = ss;
+  }
+  return NDMPS_OK;
+}
+
 extern "C" int ndmps_scale_f32(float* d_x, int64_t n, double factor, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_x && n >= 0, "bad scale argument");
   if (n == 0) return NDMPS_OK;

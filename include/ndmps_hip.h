@@ -114,6 +114,17 @@ int64_t ndmps_minmax_many_workspace_bytes(int count);
 int ndmps_minmax_many_f32(int count, const float* const* h_ptrs, const int64_t* h_lens,
                           float* h_out, double* h_sumsq, void* d_ws, int64_t ws_bytes,
                           ndmps_stream_t stream);
+
+/* The same reduction for the cores of a lockstep group sitting in one arena (row b = volume b, core i at
+ * h_offsets[i] with h_lens[i] elements; at most 64 cores), in two halves so that nothing waits in between:
+ * _launch enqueues the kernel (asynchronous; tensor (b, i) is entry b * n_cores + i), _collect copies the partials
+ * back, synchronises and folds them into (min, max) pairs and sums of squares.  core/ndmps.py:75-76 computes these
+ * eagerly; here they are issued with the sweep and read when boundary_list / norm_value are asked for. */
+int64_t ndmps_minmax_partials_bytes(int count);
+int ndmps_minmax_arena_launch_f32(const float* d_base, int64_t row_stride, int batch, int n_cores,
+                                  const int64_t* h_offsets, const int64_t* h_lens, double* d_partial,
+                                  ndmps_stream_t stream);
+int ndmps_minmax_collect(int count, const double* d_partial, float* h_out, double* h_sumsq, ndmps_stream_t stream);
 int ndmps_scale_f32(float* d_x, int64_t n, double factor, ndmps_stream_t stream);
 int64_t ndmps_reduce_workspace_bytes(void);
 

@@ -878,6 +878,31 @@ def test_to_tensors_equals_to_tensor_per_object(shape, chi, mode, count):
     assert torch.equal(NDMPS.to_tensors(objs[:1], as_torch=True)[0], one_by_one[0])
 
 
+def test_group_state_arrives_on_first_access_and_matches_the_eager_reductions():
+    """After from_tensors the min / max / norm reductions of the whole group are in flight on the device; the numbers
+    arrive when boundary_list / norm_value are first read (core/ndmps.py:75-76 computes them inside from_tensor).
+    They equal the eager per-object reductions, survive deepcopy, and values set explicitly in between win."""
+    import copy
+
+    vols = [synthetic_mri((64, 64, 64), seed=70 + i) for i in range(4)]
+    objs = NDMPS.from_tensors(vols, max_bond=16)
+    assert all(o.__dict__.get("_state_group") is not None for o in objs)  # nothing collected yet
+    objs[3].norm_value = 123.0                      # explicit value before the collection
+    clone = copy.deepcopy(objs[1])                  # collects
+    assert all(o.__dict__.get("_state_group") is None for o in objs)
+    assert objs[3].norm_value == 123.0
+    for o in objs[:3] + [clone]:
+        eager = np.array([list(v) for v in hft.minmax_many(o.mps.cores)])
+        assert np.array_equal(np.asarray(o.boundary_list), eager)
+        assert math.isclose(o.norm_value ** 2, o.mps @ o.mps, rel_tol=1e-5)
+    single = NDMPS.from_tensor(vols[0], max_bond=16)  # a single volume takes the eager path
+    assert np.array_equal(np.asarray(single.boundary_list), np.asarray(objs[0].boundary_list))
+    assert math.isclose(single.norm_value, objs[0].norm_value, rel_tol=1e-6)
+    objs[0].mps.arrays[0][:] *= 10
+    objs[0].update_boundary_list()
+    assert objs[0].boundary_list[0][1] > 5 * clone.boundary_list[0][1] or objs[0].boundary_list[0][1] > 0
+
+
 @pytest.mark.parametrize("shape,chi,mode", [((64, 64, 64), 16, "Std"), ((128, 128, 128), 64, "Std"),
                                             ((128, 128, 128), 32, "DCT"), ((64, 64, 64), 32, "DCT")], ids=str)
 def test_fused_encode_matches_permute_then_sweep(shape, chi, mode):
