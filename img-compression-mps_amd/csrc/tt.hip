@@ -519,6 +519,16 @@ inline int project_src(const __bf16*, int64_t, int64_t, int64_t, const SweepSour
   return NDMPS_EINVAL;
 }
 
+// status of the direct solver for one matrix (eig_tridiag.hip): 1 = Cholesky breakdown, 2 = a team gave up waiting
+inline int solver_failed(int site, int volume, int status) {
+  if (status == 2)
+    ndmps::set_error("site %d, volume %d: the resident tridiagonalisation gave up waiting for its workgroups (3 s; is the "
+                     "GPU shared with another process?); NDMPS_TRD_NO_TEAM=1 selects the column launches", site, volume);
+  else
+    ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", site, volume);
+  return NDMPS_ENOCONV;
+}
+
 template <typename T>
 int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, double cutoff, int64_t max_bond,
                T* const* h_cores, const int64_t* h_core_offsets, int64_t* h_bonds_out, double* h_spectra,
@@ -627,10 +637,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       NDMPS_TRY(ndmps_syevd_topk_vectors_f64(batch, eig_n.data(), kept.data(), k_cap, ev_ws, ev_ws_bytes,
                                              eig_status.data(), s));
       for (int b = 0; b < batch; ++b)
-        if (eig_status[b] != 0) {
-          ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", i, b);
-          return NDMPS_ENOCONV;
-        }
+        if (eig_status[b] != 0) return solver_failed(i, b, eig_status[b]);
     } else {
       NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(),
                                                 ev_ws, ev_ws_bytes, s));
@@ -969,10 +976,8 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));
     for (int i = 1; i < L; ++i)
       for (int b = 0; b < batch; ++b) {
-        if (host_i[(size_t)L * batch + (size_t)i * batch + b] != 0) {
-          ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", i, b);
-          return NDMPS_ENOCONV;
-        }
+        if (host_i[(size_t)L * batch + (size_t)i * batch + b] != 0)
+          return solver_failed(i, b, host_i[(size_t)L * batch + (size_t)i * batch + b]);
         h_bonds_out[(int64_t)b * (L + 1) + i] = host_i[(size_t)i * batch + b];
         if (h_spectra && h_spec_offsets) {
           const int64_t room = h_spec_offsets[i + 1] - h_spec_offsets[i];
