@@ -64,10 +64,6 @@ off = lib.ndmps_syevd_topk_stamps_offset(n, B, k)
 st = ws[off:off + 16 * 8].view(torch.int64).cpu().numpy()
 names = ["factor+fwd", "solves", "gram1", "chol1", "trsm1", "gram2", "chol2", "trsm2"]
 print("invit phases (us, matrix 0): " + ", ".join(f"{nm} {(st[i + 1] - st[i]) / 100:.1f}" for i, nm in enumerate(names)))
-if st[10:15].any():  # instrumented build of the team kernel only
-    cols = max(n - 128, 1)
-    tn = ["issue loads", "prologue", "body", "publish+ack", "meeting"]
-    print("team phases (us per column): " + ", ".join(f"{nm} {st[10 + i] / 100 / cols:.2f}" for i, nm in enumerate(tn)))
 w_trd = w.clone()
 v_trd = v.clone()
 nbj = lib.ndmps_syevj_batched_workspace_bytes(n, B)
