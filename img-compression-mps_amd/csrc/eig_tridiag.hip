@@ -1086,16 +1086,22 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   __syncthreads();  // the factors and the first forward sweep are visible to the whole workgroup
 
   // ---- the remaining sweeps: back substitution, forward sweep, back substitution.  Each is a recurrence over
-  // the rows on k lanes whose operands (three or four values per row and lane) sit in global memory: a lone
-  // lane fetching them a few rows ahead pays a memory round trip every few rows (78 us per sweep of 512 rows).
-  // Here the WHOLE workgroup streams them through a double-buffered LDS ring, two blocks of SB rows ahead of the
-  // lanes that run the recurrence, with 16-byte-coalesced loads.
+  // the rows on k lanes.  Measured on the first version (one wave doing everything: 160 ns per row) the
+  // recurrence itself was half of the time; the rest was that wave fetching and parking operands and storing its
+  // results row by row.  Now the lanes that run the recurrence touch LDS only: threads 128 .. 511 stream the
+  // operands of a block of SB rows from global memory into a double-buffered LDS ring two blocks ahead (three
+  // values per row and lane, the division of the back substitution folded into them), and carry the results of
+  // the block before from an LDS out-buffer back to Z with coalesced stores.
   {
     const int SB = kp <= 64 ? 32 : 16;
-    const int per_arr = SB * kp;               // doubles per operand array and block
-    double* ring = lds;                         // [2][4][per_arr]
-    double st0[4][4], st1[4][4];                // two register stages x 4 arrays x <= 4 elements per thread
+    const int per_arr = SB * kp;               // doubles per operand array and block (2048)
+    constexpr int HN = 384, EPT = 6;           // helper threads, elements per helper and array (EPT HN >= per_arr)
+    double* ring = lds;                         // [2][3][per_arr]
+    double* outb = lds + 6 * per_arr;           // [2][per_arr]
+    double st0[3][EPT], st1[3][EPT];            // two register stages x 3 arrays
     const bool solver = tid < k;
+    const bool helper = tid >= 128;
+    const int ht = tid - 128;
     const int c = tid;
     double xi = solver ? Z[(int64_t)(n - 1) * kp + c] : 0.0;  // last component of the fused first forward sweep
     for (int sweep = 0; sweep < 3; ++sweep) {
@@ -1104,36 +1110,45 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
       const int nblk = (rows + SB - 1) / SB;
       // row visited at position s of block blk (may be out of range: < 0 or > n-2)
       auto row_of = [&](int blk, int s2) { return backward ? (n - 2) - blk * SB - s2 : blk * SB + s2; };
-      auto fetch = [&](int blk, double (&dst)[4][4]) {
+      auto fetch = [&](int blk, double (&dst)[3][EPT]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = tid + 512 * u;
+        for (int u = 0; u < EPT; ++u) {
+          const int e = ht + HN * u;
           const int s2 = e / kp, cc = e % kp;
           const int r = row_of(blk, s2);
           const bool ok = e < per_arr && blk < nblk && r >= 0 && r <= n - 2;
           const int64_t o = (int64_t)(ok ? r : 0) * kp + cc;
-          if (backward) {
-            dst[0][u] = ok ? Z[o] : 0.0;
-            dst[1][u] = ok ? DU[o] : 0.0;
-            dst[2][u] = ok ? DU2[o] : 0.0;
-            dst[3][u] = ok ? DI[o] : 1.0;
+          if (backward) {  // x_r = (z_r - du_r x_{r+1} - du2_r x_{r+2}) / d_r, the division folded in
+            const double di = ok ? DI[o] : 0.0;
+            dst[0][u] = ok ? Z[o] * di : 0.0;
+            dst[1][u] = ok ? DU[o] * di : 0.0;
+            dst[2][u] = ok ? DU2[o] * di : 0.0;
           } else {
             dst[0][u] = ok ? Z[o + kp] : 0.0;
             dst[1][u] = ok ? DL[o] : 0.0;
             dst[2][u] = (ok && PV[o] != 0) ? 1.0 : 0.0;
-            dst[3][u] = 0.0;
           }
         }
       };
-      auto commit = [&](int blk, const double (&src)[4][4]) {
-        double* buf = ring + (blk & 1) * 4 * per_arr;
+      auto commit = [&](int blk, const double (&src)[3][EPT]) {
+        double* buf = ring + (blk & 1) * 3 * per_arr;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = tid + 512 * u;
+        for (int u = 0; u < EPT; ++u) {
+          const int e = ht + HN * u;
           if (e < per_arr) {
 #pragma unroll
-            for (int a2 = 0; a2 < 4; ++a2) buf[a2 * per_arr + e] = src[a2][u];
+            for (int a2 = 0; a2 < 3; ++a2) buf[a2 * per_arr + e] = src[a2][u];
           }
+        }
+      };
+      auto write_back = [&](int blk) {  // results of block blk: LDS -> Z
+        const double* ob = outb + (blk & 1) * per_arr;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+          const int e = ht + HN * u;
+          const int s2 = e / kp, cc = e % kp;
+          const int r = row_of(blk, s2);
+          if (e < per_arr && cc < k && r >= 0 && r <= n - 2) Z[(int64_t)r * kp + cc] = ob[e];
         }
       };
       double x1 = 0.0, x2 = 0.0;
@@ -1146,45 +1161,47 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
         xi = Z[c];
       }
       __syncthreads();  // the previous sweep's stores are visible; the ring is free
-      fetch(0, st0);
-      fetch(1, st1);
-      commit(0, st0);
+      if (helper) {
+        fetch(0, st0);
+        fetch(1, st1);
+        commit(0, st0);
+      }
       __syncthreads();
       // The stage holding block blk + 1 (fetched two iterations ago) is parked in the other LDS buffer, then
       // reused for block blk + 2.  The stages are named, not indexed: a run-time index would put them in scratch.
-      auto iteration = [&](int blk, double (&parked)[4][4], double (&refill)[4][4]) {
-        if (blk + 1 < nblk) commit(blk + 1, parked);
-        fetch(blk + 2, refill);
-        if (solver) {
-          const double* buf = ring + (blk & 1) * 4 * per_arr + c;
+      auto iteration = [&](int blk, double (&parked)[3][EPT], double (&refill)[3][EPT]) {
+        if (helper) {
+          if (blk + 1 < nblk) commit(blk + 1, parked);
+          fetch(blk + 2, refill);
+          if (blk >= 1) write_back(blk - 1);
+        } else if (solver) {
+          const double* buf = ring + (blk & 1) * 3 * per_arr + c;
+          double* ob = outb + (blk & 1) * per_arr + c;
           for (int s0 = 0; s0 < SB; s0 += CH) {  // eight rows' operands out of LDS, then eight steps of the chain
-            double o0[CH], o1[CH], o2[CH], o3[CH];
+            double o0[CH], o1[CH], o2[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
               const int e = (s0 + u) * kp;
               o0[u] = buf[e];
               o1[u] = buf[per_arr + e];
               o2[u] = buf[2 * per_arr + e];
-              o3[u] = buf[3 * per_arr + e];
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
               const int r = row_of(blk, s0 + u);
               const bool in = r >= 0 && r <= n - 2;
               if (backward) {
-                const double x0 = (o0[u] - o1[u] * x1 - o2[u] * x2) * o3[u];
+                const double x0 = fma(-o1[u], x1, fma(-o2[u], x2, o0[u]));
+                ob[(s0 + u) * kp] = x0;
                 if (in) {
-                  Z[(int64_t)r * kp + c] = x0;
                   x2 = x1;
                   x1 = x0;
                 }
               } else {
                 const bool sw = o2[u] != 0.0;
                 const double top = sw ? o0[u] : xi, bot = sw ? xi : o0[u];
-                if (in) {
-                  Z[(int64_t)r * kp + c] = top;
-                  xi = fma(-o1[u], top, bot);
-                }
+                ob[(s0 + u) * kp] = top;
+                if (in) xi = fma(-o1[u], top, bot);
               }
             }
           }
@@ -1195,6 +1212,8 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
         iteration(blk, st1, st0);
         if (blk + 1 < nblk) iteration(blk + 1, st0, st1);
       }
+      if (helper) write_back(nblk - 1);
+      __syncthreads();  // the sweep's results are in Z before the next one (or the orthonormalisation) reads them
     }
   }
   // pad columns of the block stay zero
