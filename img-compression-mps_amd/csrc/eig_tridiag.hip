@@ -408,11 +408,12 @@ __device__ __forceinline__ unsigned long long team_poll(const unsigned long long
 // and a consumer's use, instead of store acknowledgement + counter update + counter poll + data load.  The records
 // of a matrix are double-buffered by the parity of the column like the plain vectors: nobody can be two columns
 // ahead of anybody, because publishing column j + 2 needs everybody's column j + 1.
-template <int NR, bool TAGGED>
+// CW: columns per workgroup, 32 (16 workgroups per order-512 matrix) or 8 (64 of them, for one to four matrices:
+// the tile loop is a quarter as long, the per-column arithmetic of the slowest member shrinks with it).
+template <int NR, bool TAGGED, int CW = 32>
 __global__ void __launch_bounds__(256, 2)
 trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
-  constexpr int CW = 32;             // columns per workgroup
-  constexpr int LPR = 8;             // lanes per row, 4 columns (32 bytes) each
+  constexpr int LPR = CW / 4;        // lanes per row, 4 columns (32 bytes) each
   constexpr int RPW = 64 / LPR;      // rows per wave instruction
   constexpr int RPI = 4 * RPW;       // rows per tile of the workgroup
   constexpr int NT = 512 / RPI;      // tiles per lane: 512 rows
@@ -1930,9 +1931,11 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
   if (team) {
     // a launch never holds more workgroups than the device keeps resident at once: no team then depends on the
     // order in which the dispatcher places workgroups (larger batches go in several launches)
-    const int team_size = (int)ndmps::ceil_div(n_max, 32);
     int slots = 0;
     NDMPS_TRY(team_slots(slots));
+    // one to four matrices: 8-column blocks (64 workgroups per order-512 matrix, one per CU)
+    const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= slots && !getenv("NDMPS_TRD_TEAM_WIDE");
+    const int team_size = (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
     const int per_launch = std::max(1, slots / team_size);
     NDMPS_TRY(team_launch(s, [&]() {
       static std::atomic<unsigned> epoch_counter{1};
@@ -1945,7 +1948,8 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
       for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const unsigned epoch = epoch_counter.fetch_add(1);
         const dim3 grid((unsigned)team_size, (unsigned)std::min(per_launch, batch - b0));
-        if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, w, b0, epoch);
+        if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, w, b0, epoch);
+        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, w, b0, epoch);
         else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, w, b0, epoch);
       }
     }));
