@@ -121,6 +121,26 @@ SIGNATURES = {
     "ndmps_psnr_f32": (C.c_int, [vp, vp, i64, p_f64, vp, i64, vp]),
     "ndmps_quantize_f32": (C.c_int, [vp, i64, C.c_float, C.c_float, C.c_int, vp, vp]),
     "ndmps_dequantize_f32": (C.c_int, [vp, i64, C.c_float, C.c_float, C.c_int, vp, vp]),
+    # fp64 storage (the reference's own element type)
+    "ndmps_gram_f64_workspace_bytes": (i64, [i64, i64]),
+    "ndmps_gram_f64": (C.c_int, [vp, i64, i64, i64, vp, vp, i64, vp]),
+    "ndmps_tt_sweep_batched_workspace_bytes_f64": (i64, [C.c_int, C.c_int, p_i64, i64]),
+    "ndmps_tt_sweep_batched_f64": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
+                                             C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, i64, vp]),
+    "ndmps_compress_bond_f64": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, C.c_double, i64, vp, vp,
+                                          p_i64, p_f64, vp, i64, vp]),
+    "ndmps_chain_workspace_bytes_f64": (i64, [C.c_int, p_i64, p_i64]),
+    "ndmps_chain_contract_f64": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), vp, vp, i64, vp]),
+    "ndmps_overlap_f64": (C.c_int, [C.c_int, p_i64, p_i64, C.POINTER(vp), p_i64, C.POINTER(vp), p_f64,
+                                    vp, i64, vp]),
+    "ndmps_sumsq_f64": (C.c_int, [vp, i64, p_f64, vp, i64, vp]),
+    "ndmps_scale_f64": (C.c_int, [vp, i64, C.c_double, vp]),
+    "ndmps_minmax_many_f64": (C.c_int, [C.c_int, C.POINTER(vp), p_i64, p_f64, p_f64, vp, i64, vp]),
+    "ndmps_dct_basis_f64": (C.c_int, [vp, i64, vp]),
+    "ndmps_dct_last_f64": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ndmps_idct_last_f64": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ndmps_quantize_f64": (C.c_int, [vp, i64, C.c_double, C.c_double, C.c_int, vp, vp]),
+    "ndmps_dequantize_f64": (C.c_int, [vp, i64, C.c_double, C.c_double, C.c_int, vp, vp]),
 }
 
 _lib = None

@@ -48,13 +48,16 @@ class DeviceCore:
 
     @property
     def dtype(self):
-        return np.dtype(np.float32)
+        return np.dtype(np.float64 if self.tensor.dtype == _torch().float64 else np.float32)
 
     def __len__(self):
         return self.tensor.shape[0]
 
     def __array__(self, dtype=None, copy=None):
-        arr = self.tensor.detach().float().cpu().numpy()  # bf16 cores read as fp32 (NumPy has no bf16)
+        t = self.tensor.detach()
+        if t.dtype != _torch().float64:
+            t = t.float()  # bf16 cores read as fp32 (NumPy has no bf16)
+        arr = t.cpu().numpy()
         return arr.astype(dtype) if dtype is not None else arr
 
     def numpy(self):
@@ -136,7 +139,7 @@ class _Site:
 
 
 class DeviceMPS:
-    """Open-boundary MPS with fp32 cores ``(chi_i, d_i, chi_{i+1})`` in HBM."""
+    """Open-boundary MPS with cores ``(chi_i, d_i, chi_{i+1})`` in HBM (fp32; bf16 or fp64 storage on request)."""
 
     def __init__(self, cores, _trusted=False):
         if _trusted:  # cores made by the sweep: contiguous 3-D views already
@@ -212,6 +215,11 @@ class DeviceMPS:
         keep = [c if c.dtype == torch.float32 else c.to(torch.float32) for c in self.cores]
         return keep, (C.c_void_p * len(keep))(*[c.data_ptr() for c in keep])
 
+    def _f64_ptrs(self):
+        torch = _torch()
+        keep = [c if c.dtype == torch.float64 else c.to(torch.float64) for c in self.cores]
+        return keep, (C.c_void_p * len(keep))(*[c.data_ptr() for c in keep])
+
     @property
     def dtype(self):
         return self.cores[0].dtype
@@ -228,10 +236,15 @@ class DeviceMPS:
         nbytes = lib.ndmps_overlap_workspace_bytes(L, dims, ba, bb)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         out = C.c_double()
-        keep_a, pa = self._f32_ptrs()
-        keep_b, pb = other._f32_ptrs()
-        _lib.check(lib.ndmps_overlap_f32(L, dims, ba, pa, bb, pb, C.byref(out), ws.data_ptr(), nbytes,
-                                         _lib.stream_ptr()))
+        if self.dtype == torch.float64 or other.dtype == torch.float64:
+            keep_a, pa = self._f64_ptrs()  # fp64 cores are contracted as they are (a mixed pair: upcast)
+            keep_b, pb = other._f64_ptrs()
+            fn = lib.ndmps_overlap_f64
+        else:
+            keep_a, pa = self._f32_ptrs()
+            keep_b, pb = other._f32_ptrs()
+            fn = lib.ndmps_overlap_f32
+        _lib.check(fn(L, dims, ba, pa, bb, pb, C.byref(out), ws.data_ptr(), nbytes, _lib.stream_ptr()))
         del keep_a, keep_b
         return float(out.value)
 
@@ -245,9 +258,11 @@ class DeviceMPS:
         numel = int(np.prod(self.dims, dtype=np.int64))
         if out is None:
             out = torch.empty(numel, dtype=self.dtype, device=self.device)
-        nbytes = lib.ndmps_chain_workspace_bytes(L, dims, bonds)
+        f64 = self.dtype == torch.float64
+        nbytes = (lib.ndmps_chain_workspace_bytes_f64 if f64 else lib.ndmps_chain_workspace_bytes)(L, dims, bonds)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        fn = lib.ndmps_chain_contract_bf16 if self.dtype == torch.bfloat16 else lib.ndmps_chain_contract_f32
+        fn = (lib.ndmps_chain_contract_f64 if f64 else
+              lib.ndmps_chain_contract_bf16 if self.dtype == torch.bfloat16 else lib.ndmps_chain_contract_f32)
         _lib.check(fn(L, dims, bonds, self._core_ptrs(), out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr()))
         return out
 
@@ -268,20 +283,22 @@ class DeviceMPS:
 
     def compress_bond_(self, i, cutoff, max_bond=None):
         """tensor_compress_bond on bond (i-1, i) (core/ndmps.py:104-106); returns the spectrum.  bf16 cores
-        are truncated in fp32 and stored back as bf16."""
+        are truncated in fp32 and stored back as bf16, fp64 cores in fp64."""
         torch = _torch()
         lib = _lib.load()
         store = self.dtype
-        t1, t2 = self.cores[i - 1].to(torch.float32), self.cores[i].to(torch.float32)
+        work = torch.float64 if store == torch.float64 else torch.float32
+        t1, t2 = self.cores[i - 1].to(work), self.cores[i].to(work)
         chi_l, d1, chi = (int(v) for v in t1.shape)
         _, d2, chi_r = (int(v) for v in t2.shape)
         nbytes = lib.ndmps_compress_bond_workspace_bytes(chi_l, d1, chi, d2, chi_r)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        new1 = torch.empty(chi_l * d1 * chi, dtype=torch.float32, device=self.device)
-        new2 = torch.empty(chi * d2 * chi_r, dtype=torch.float32, device=self.device)
+        new1 = torch.empty(chi_l * d1 * chi, dtype=work, device=self.device)
+        new2 = torch.empty(chi * d2 * chi_r, dtype=work, device=self.device)
         k = C.c_int64()
         spec = (C.c_double * chi)()
-        _lib.check(lib.ndmps_compress_bond_f32(
+        fn = lib.ndmps_compress_bond_f64 if work == torch.float64 else lib.ndmps_compress_bond_f32
+        _lib.check(fn(
             t1.data_ptr(), t2.data_ptr(), chi_l, d1, chi, d2, chi_r, float(cutoff),
             int(max_bond) if max_bond else 0, new1.data_ptr(), new2.data_ptr(), C.byref(k), spec,
             ws.data_ptr(), nbytes, _lib.stream_ptr()))

@@ -158,13 +158,14 @@ def _plan_for(shape, device_index):
         return _PLAN_CACHE[key]
 
 
-def _dct_basis(n, device):
+def _dct_basis(n, device, f64=False):
     torch = _torch()
-    key = (int(n), str(device))
+    key = (int(n), str(device), bool(f64))
     with _CACHE_LOCK:
         if key not in _DCT_CACHE:
-            basis = torch.empty((n, n), dtype=torch.float32, device=device)
-            _lib.check(_lib.load().ndmps_dct_basis_f32(basis.data_ptr(), n, _lib.stream_ptr()))
+            basis = torch.empty((n, n), dtype=torch.float64 if f64 else torch.float32, device=device)
+            fill = _lib.load().ndmps_dct_basis_f64 if f64 else _lib.load().ndmps_dct_basis_f32
+            _lib.check(fill(basis.data_ptr(), n, _lib.stream_ptr()))
             # the basis is shared by every stream from now on: finish the fill before publishing it
             torch.cuda.current_stream().synchronize()
             _DCT_CACHE[key] = basis
@@ -310,7 +311,8 @@ class NDMPS:
         mode : "Std" for raw encoding or "DCT" for last-axis DCT preprocessing.
         max_bond : optional bond cap chi applied during the sweep (None = exact sweep).
         cutoff : relative singular-value cutoff of the sweep (quimb from_dense default).
-        dtype : storage type in HBM, ``torch.float32`` (default) or ``torch.bfloat16`` (see from_tensors).
+        dtype : storage type in HBM, ``torch.float32`` (default), ``torch.bfloat16`` or ``torch.float64``
+            (the reference's own element type; see from_tensors).
         """
         return cls.from_tensors([tensor], norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff,
                                 device=device, dtype=dtype)[0]
@@ -332,6 +334,13 @@ class NDMPS:
         ``to_tensor`` then contracts in bf16 as well.  Results carry bf16 rounding (2^-9 relative per
         stored value).
 
+        ``dtype=torch.float64`` selects fp64 STORAGE, the reference's own element type (ndmps.py:56): volume,
+        carried matrices and cores are fp64 in HBM, every product runs on the fp64 MFMA, norm / DCT / overlap /
+        truncation / quantisation are fp64 as well, and ``to_tensor`` returns float64 -- the mode that meets the
+        reference's own tolerances (round trip 1e-10, norms 1e-12).  A fidelity mode: several times slower than
+        fp32 storage.  The sweep's relative cutoff is clamped below at 1e-8 (singular values come from fp64 Gram
+        matrices).
+
         ``reconstruct=True`` returns ``(objects, reconstructions)``: the chain products of the whole list are issued
         as soon as the sweep has returned, BEFORE the Python objects are built (their construction then runs
         under the decode instead of in front of it); the reconstructions (device tensors) equal
@@ -350,10 +359,11 @@ class NDMPS:
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         store = torch.float32 if dtype is None else dtype
-        if store not in (torch.float32, torch.bfloat16):
-            raise ValueError("storage dtype must be torch.float32 or torch.bfloat16")
+        if store not in (torch.float32, torch.bfloat16, torch.float64):
+            raise ValueError("storage dtype must be torch.float32, torch.bfloat16 or torch.float64")
         bf16 = store == torch.bfloat16
-        esize = 2 if bf16 else 4
+        f64 = store == torch.float64
+        esize = 2 if bf16 else (8 if f64 else 4)
         xs = []
         for tensor in tensors:
             if isinstance(tensor, torch.Tensor):
@@ -373,7 +383,8 @@ class NDMPS:
                     raise ValueError("Shape cannot be empty.")
                 if arr.dtype.kind not in "fiub":
                     raise TypeError(f"unsupported tensor dtype {arr.dtype}")
-                x = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device).to(store)
+                host_type = np.float64 if f64 else np.float32
+                x = torch.from_numpy(np.ascontiguousarray(arr, dtype=host_type)).to(device).to(store)
             xs.append(x)
         shape = tuple(int(v) for v in xs[0].shape)
         if any(tuple(x.shape) != shape for x in xs):
@@ -389,7 +400,7 @@ class NDMPS:
             mb = int(max_bond) if max_bond else 0
             # fp32, bond-capped: the reshape stage rides on the first Gram pass and the first projection of the
             # sweep (the volume is read through the permutation tables, no site-order tensor is formed)
-            n_merge = 0 if (bf16 or os.environ.get("NDMPS_NO_FUSED_ENCODE")) else int(lib.ndmps_tt_merge_columns(L, cdims, mb))
+            n_merge = 0 if (bf16 or f64 or os.environ.get("NDMPS_NO_FUSED_ENCODE")) else int(lib.ndmps_tt_merge_columns(L, cdims, mb))
             gather = plan.gather_tables(n_merge, device) if n_merge > 0 else None
             denses = []
             for x in xs:
@@ -398,13 +409,14 @@ class NDMPS:
                 if norm:
                     ws = torch.empty(lib.ndmps_reduce_workspace_bytes(), dtype=torch.uint8, device=device)
                     ss = C.c_double()
-                    _lib.check(lib.ndmps_sumsq_f32(x.data_ptr(), numel, C.byref(ss), ws.data_ptr(), ws.numel(), stream))
-                    _lib.check(lib.ndmps_scale_f32(x.data_ptr(), numel, 1.0 / float(np.sqrt(ss.value)), stream))
+                    sumsq, scale = (lib.ndmps_sumsq_f64, lib.ndmps_scale_f64) if f64 else (lib.ndmps_sumsq_f32, lib.ndmps_scale_f32)
+                    _lib.check(sumsq(x.data_ptr(), numel, C.byref(ss), ws.data_ptr(), ws.numel(), stream))
+                    _lib.check(scale(x.data_ptr(), numel, 1.0 / float(np.sqrt(ss.value)), stream))
                 if mode == "DCT":
                     n = shape[-1]
                     y = torch.empty_like(x)
-                    _lib.check(lib.ndmps_dct_last_f32(x.data_ptr(), y.data_ptr(), numel // n, n,
-                                                      _dct_basis(n, device).data_ptr(), stream))
+                    dct = lib.ndmps_dct_last_f64 if f64 else lib.ndmps_dct_last_f32
+                    _lib.check(dct(x.data_ptr(), y.data_ptr(), numel // n, n, _dct_basis(n, device, f64).data_ptr(), stream))
                     x = y
                 x = x.to(store)
                 if gather is not None:
@@ -420,7 +432,8 @@ class NDMPS:
             core_off = (C.c_int64 * (L + 1))()
             spec_off = (C.c_int64 * (L + 1))()
             _lib.check(lib.ndmps_tt_layout(L, cdims, mb, max_bonds, core_off, spec_off, None))
-            ws_bytes = lib.ndmps_tt_sweep_batched_workspace_bytes(batch, L, cdims, mb)
+            ws_query = lib.ndmps_tt_sweep_batched_workspace_bytes_f64 if f64 else lib.ndmps_tt_sweep_batched_workspace_bytes
+            ws_bytes = ws_query(batch, L, cdims, mb)
             if ws_bytes < 0:
                 _lib.check(_lib.EINVAL)
             # one arena for the group: volume b's cores at row b (views of it are what the objects keep)
@@ -441,7 +454,8 @@ class NDMPS:
                         row_off.data_ptr(), col_off.data_ptr(), col_perm.data_ptr(), n_merge, ws.data_ptr(), ws.numel(),
                         stream))
                 else:
-                    sweep = lib.ndmps_tt_sweep_batched_bf16 if bf16 else lib.ndmps_tt_sweep_batched_f32
+                    sweep = (lib.ndmps_tt_sweep_batched_bf16 if bf16 else
+                             lib.ndmps_tt_sweep_batched_f64 if f64 else lib.ndmps_tt_sweep_batched_f32)
                     _lib.check(sweep(batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds,
                                      spectra, spec_off, ws.data_ptr(), ws.numel(), stream))
             del ws, denses
@@ -454,7 +468,7 @@ class NDMPS:
             offs = [int(core_off[i]) for i in range(L + 1)]
             spec_offs = [int(spec_off[i]) for i in range(L + 1)]
             recs = None
-            n_tail = int(lib.ndmps_chain_tail_columns(L, cdims)) if (reconstruct and not bf16 and batch > 1) else 0
+            n_tail = int(lib.ndmps_chain_tail_columns(L, cdims)) if (reconstruct and not bf16 and not f64 and batch > 1) else 0
             if n_tail > 0 and not os.environ.get("NDMPS_NO_FUSED_DECODE"):
                 # decode straight from the arena: padded cores are valid cores of the cap bonds (zeros beyond the rank)
                 dec_bonds = (C.c_int64 * (batch * (L + 1)))()
@@ -531,7 +545,7 @@ class NDMPS:
                 # launch.  The sweep leaves sites 1..L-1 right-isometric (rows of V^T), so
                 # mps @ mps = ||site 0||_F^2 up to the fp32 rounding of those rows (~1e-7 relative);
                 # update_norm() evaluates the full overlap contraction like the reference.
-                if per_site is not None and not bf16 and L <= 64 and batch * L <= 65535:
+                if per_site is not None and not bf16 and not f64 and L <= 64 and batch * L <= 65535:
                     # cores = cap-shaped views of the arena: one launch now, the numbers on first access
                     count = batch * L
                     partial = torch.empty(int(lib.ndmps_minmax_partials_bytes(count)) // 8, dtype=torch.float64, device=device)
@@ -619,7 +633,8 @@ class NDMPS:
         Convert MPS back to tensor format (with optional inverse DCT).
 
         Returns a NumPy array like the reference; ``as_torch=True`` keeps the result in HBM and
-        ``dtype`` (e.g. ``torch.bfloat16``) selects its storage type (arithmetic stays fp32).
+        ``dtype`` (e.g. ``torch.bfloat16``) selects its storage type (arithmetic stays fp32).  fp64 cores
+        (``from_tensor(dtype=torch.float64)``) are contracted on the fp64 MFMA and give a float64 result.
         """
         torch = _torch()
         lib = _lib.load()
@@ -647,15 +662,19 @@ class NDMPS:
                                                         dense.element_size(), stream))
             if self.mode == "DCT":
                 n = self._shape[-1]
-                out = out.to(torch.float32)  # the IDCT kernel is fp32 (bf16 storage: upcast copy)
+                f64 = out.dtype == torch.float64
+                if not f64:
+                    out = out.to(torch.float32)  # the IDCT kernel is fp32 (bf16 storage: upcast copy)
                 rec = torch.empty_like(out)
-                _lib.check(lib.ndmps_idct_last_f32(out.data_ptr(), rec.data_ptr(), plan.numel // n, n,
-                                                   _dct_basis(n, device).data_ptr(), stream))
+                idct = lib.ndmps_idct_last_f64 if f64 else lib.ndmps_idct_last_f32
+                _lib.check(idct(out.data_ptr(), rec.data_ptr(), plan.numel // n, n, _dct_basis(n, device, f64).data_ptr(), stream))
                 out = rec
             elif self.mode != "Std":
                 return None  # ndmps.py:150-153: unknown modes fall through
         if as_torch:
             return out if dtype is None else out.to(dtype)
+        if out.dtype == torch.float64:
+            return out.cpu().numpy()
         return out.to(torch.float32).cpu().numpy()  # NumPy has no bf16
 
     @staticmethod
@@ -725,7 +744,8 @@ class NDMPS:
         arrays = self.mps.arrays
         q_dev = [_ft.scale_to_dtype(a.tensor, dtype) for a in arrays]
         if replace:
-            back = [_ft.scale_back(q, b[0], b[1], dtype) for q, b in zip(q_dev, self.boundary_list)]
+            back = [_ft.scale_back(q, b[0], b[1], dtype, out_dtype=a.tensor.dtype)
+                    for q, b, a in zip(q_dev, self.boundary_list, arrays)]
             self.replace_tensordata(back)
         return [_ft.to_numpy_uint(q, dtype) for q in q_dev]
 

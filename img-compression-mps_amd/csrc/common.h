@@ -61,6 +61,15 @@ static inline int64_t arena_bytes(int64_t used, int64_t elem, int64_t count) {
 
 constexpr int kNumCU = 256;  // MI355X
 
+// element conversions of the storage types (fp32, bf16, fp64) to and from the fp64 side of the path
+__device__ __forceinline__ double to_f64(float x) { return (double)x; }
+__device__ __forceinline__ double to_f64(__bf16 x) { return (double)(float)x; }
+__device__ __forceinline__ double to_f64(double x) { return x; }
+template <typename T>
+__device__ __forceinline__ T from_f64(double x) { return (T)(float)x; }
+template <>
+__device__ __forceinline__ double from_f64<double>(double x) { return x; }
+
 // launch spans for bench.py's roofline (util.hip); slot ids
 constexpr int kSpanTridiagColumns = 1;
 constexpr int kSpanTridiagTeam = 2;

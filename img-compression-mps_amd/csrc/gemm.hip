@@ -506,8 +506,8 @@ gram_partial_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda
     for (int a = 0; a < T; ++a) {
       const int64_t ca = i0 + 16 * a + lc;
       const int64_t cb = j0 + 16 * a + lc;
-      av[a] = (row_ok && ca < n) ? (double)(float)A[row * lda + ca] : 0.0;
-      bv[a] = (row_ok && cb < n) ? (double)(float)A[row * lda + cb] : 0.0;
+      av[a] = (row_ok && ca < n) ? ndmps::to_f64(A[row * lda + ca]) : 0.0;
+      bv[a] = (row_ok && cb < n) ? ndmps::to_f64(A[row * lda + cb]) : 0.0;
     }
 #pragma unroll
     for (int a = 0; a < T; ++a)
@@ -1452,6 +1452,44 @@ extern "C" int ndmps_gram_batched_indexed_f32(int batch, const float* const* h_b
   NDMPS_REQUIRE(d_row_off && d_col_off, "NULL offset table");
   return gram128_batched<float>(batch, h_base, m, n, n, d_G, stride_G, d_ws, ws_bytes, (hipStream_t)stream, d_row_off,
                                 d_col_off);
+}
+
+// fp64 storage (the reference's own element type, core/ndmps.py:56): the matrix is read as fp64 straight from global
+// memory by the tile kernel without LDS staging (64 x 64 tiles of the upper triangle x row slabs) -- a fidelity
+// mode, not the throughput path.  Products of two fp64 numbers are rounded: G carries ~sqrt(m) eps relative error.
+extern "C" int64_t ndmps_gram_f64_workspace_bytes(int64_t m, int64_t n) {
+  if (m <= 0 || n <= 0) return 0;
+  GramGeom g = gram_geometry(m, n);
+  const int ts = 16 * g.T;
+  return (int64_t)(g.n_slabs + g.n_slabs / kReduceGroup + 2) * g.n_tiles * ts * ts * (int64_t)sizeof(double) + 256;
+}
+extern "C" int ndmps_gram_f64(const double* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, void* d_ws,
+                              int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_A && d_G, "NULL Gram operand");
+  NDMPS_REQUIRE(m > 0 && n > 0 && lda >= n, "bad Gram extents m=%lld n=%lld lda=%lld", (long long)m, (long long)n,
+                (long long)lda);
+  if (ws_bytes < ndmps_gram_f64_workspace_bytes(m, n) || d_ws == nullptr) {
+    ndmps::set_error("Gram workspace too small: %lld < %lld", (long long)ws_bytes,
+                     (long long)ndmps_gram_f64_workspace_bytes(m, n));
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = (double*)d_ws;
+  GramGeom g = gram_geometry(m, n);
+  NDMPS_REQUIRE(g.n_slabs < 65536, "Gram slab count %d exceeds grid.y", g.n_slabs);
+  dim3 grid(g.n_tiles, g.n_slabs);
+#define NDMPS_GRAM64(TT)                                                                               \
+  do {                                                                                                 \
+    hipLaunchKernelGGL((gram_partial_kernel<TT, double>), grid, dim3(256), 0, s, d_A, m, n, lda, partial, \
+                       g.tiles_1d, g.rows_per_slab);                                                   \
+    NDMPS_LAUNCH_CHECK();                                                                              \
+    return launch_tile_reduce<16 * TT>(partial, g.n_slabs, g.tiles_1d, g.n_tiles, d_G, n, s);          \
+  } while (0)
+  if (g.T == 1) NDMPS_GRAM64(1);
+  else if (g.T == 2) NDMPS_GRAM64(2);
+  else NDMPS_GRAM64(4);
+#undef NDMPS_GRAM64
+  return NDMPS_OK;
 }
 
 // same with a bf16 matrix (products of two bf16 numbers are exact in fp32, let alone fp64)

@@ -29,8 +29,9 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // stage 1: per-block partials (fixed grid -> deterministic), stage 2: one block folds them
+template <typename T>
 __global__ void __launch_bounds__(256)
-sumsq_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
+sumsq_partial_kernel(const T* __restrict__ x, int64_t n, double* __restrict__ partial) {
   __shared__ double red[4];
   double acc = 0.0;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -140,14 +141,50 @@ minmax_many_kernel(const float* const* __restrict__ ptrs, const int64_t* __restr
   }
 }
 
-__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, int64_t n, double factor) {
+template <typename T>
+__global__ void __launch_bounds__(256) scale_kernel(T* __restrict__ x, int64_t n, double factor) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-    x[i] = (float)((double)x[i] * factor);
+    x[i] = (T)((double)x[i] * factor);
+}
+
+// fp64 tensors: (min, max, sum of squares) per slice, as three doubles (twin of minmax_many_kernel)
+__global__ void __launch_bounds__(256)
+minmax_many_f64_kernel(const double* const* __restrict__ ptrs, const int64_t* __restrict__ lens,
+                       double* __restrict__ partial) {
+  __shared__ double rmin[4], rmax[4], rsum[4];
+  const double* x = ptrs[blockIdx.y];
+  const int64_t n = lens[blockIdx.y];
+  double lo = DBL_MAX, hi = -DBL_MAX, ss = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const double v = x[i];
+    lo = fmin(lo, v);
+    hi = fmax(hi, v);
+    ss += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_down(lo, off, 64));
+    hi = fmax(hi, __shfl_down(hi, off, 64));
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) {
+    rmin[threadIdx.x >> 6] = lo;
+    rmax[threadIdx.x >> 6] = hi;
+    rsum[threadIdx.x >> 6] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = partial + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = fmin(fmin(rmin[0], rmin[1]), fmin(rmin[2], rmin[3]));
+    o[1] = fmax(fmax(rmax[0], rmax[1]), fmax(rmax[2], rmax[3]));
+    o[2] = (rsum[0] + rsum[1]) + (rsum[2] + rsum[3]);
+  }
 }
 
 // forward basis B[j][k] = s_k cos(pi (2j+1) k / (2n)); y = x B is the orthonormal DCT-II
-__global__ void __launch_bounds__(256) dct_basis_kernel(float* __restrict__ basis, int64_t n) {
+template <typename T>
+__global__ void __launch_bounds__(256) dct_basis_kernel(T* __restrict__ basis, int64_t n) {
   const int64_t total = n * n;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
@@ -155,13 +192,13 @@ __global__ void __launch_bounds__(256) dct_basis_kernel(float* __restrict__ basi
     const int64_t num = ((2 * j + 1) * k) % (4 * n);  // angle = pi * num / (2n), period 4n
     const double c = cospi((double)num / (double)(2 * n));
     const double sk = (k == 0) ? sqrt(1.0 / (double)n) : sqrt(2.0 / (double)n);
-    basis[e] = (float)(sk * c);
+    basis[e] = (T)(sk * c);
   }
 }
 
-template <typename Q>
+template <typename Q, typename T = float>
 __global__ void __launch_bounds__(256)
-quantize_kernel(const float* __restrict__ x, int64_t n, double lo, double span, double qmax,
+quantize_kernel(const T* __restrict__ x, int64_t n, double lo, double span, double qmax,
                 Q* __restrict__ q) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -171,13 +208,17 @@ quantize_kernel(const float* __restrict__ x, int64_t n, double lo, double span, 
   }
 }
 
-template <typename Q>
+template <typename Q, typename T = float>
 __global__ void __launch_bounds__(256)
 dequantize_kernel(const Q* __restrict__ q, int64_t n, double lo, double span, double qmax,
-                  float* __restrict__ x) {
+                  T* __restrict__ x) {
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-    x[i] = (float)(((double)q[i] / qmax) * span + lo);  // filetools.py:38-39
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+#pragma clang fp contract(off)  // filetools.py:38-39 multiplies, then adds: two roundings, not one FMA
+    const double unit = (double)q[i] / qmax;
+    const double scaled = unit * span;
+    x[i] = (T)(scaled + lo);
+  }
 }
 
 int stream_grid(int64_t n) {
@@ -188,8 +229,9 @@ int stream_grid(int64_t n) {
 
 extern "C" int64_t ndmps_reduce_workspace_bytes(void) { return kRedBlocks * 2 * sizeof(double) + 512; }
 
-extern "C" int ndmps_sumsq_f32(const float* d_x, int64_t n, double* h_out, void* d_ws, int64_t ws_bytes,
-                               ndmps_stream_t stream) {
+namespace {
+template <typename T>
+int sumsq_impl(const T* d_x, int64_t n, double* h_out, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_x && h_out && n >= 0, "bad sumsq argument");
   if (!d_ws || ws_bytes < ndmps_reduce_workspace_bytes()) {
     ndmps::set_error("reduce workspace too small");
@@ -199,12 +241,22 @@ extern "C" int ndmps_sumsq_f32(const float* d_x, int64_t n, double* h_out, void*
   double* partial = (double*)d_ws;
   double* result = partial + kRedBlocks;
   const int grid = (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(n, 256 * 8), 1), kRedBlocks);
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, s, d_x, n, partial);
+  hipLaunchKernelGGL(sumsq_partial_kernel<T>, dim3(grid), dim3(256), 0, s, d_x, n, partial);
   hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, s, partial, grid, result);
   NDMPS_LAUNCH_CHECK();
   NDMPS_CHECK_HIP(hipMemcpyAsync(h_out, result, sizeof(double), hipMemcpyDeviceToHost, s));
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   return NDMPS_OK;
+}
+}  // namespace
+
+extern "C" int ndmps_sumsq_f32(const float* d_x, int64_t n, double* h_out, void* d_ws, int64_t ws_bytes,
+                               ndmps_stream_t stream) {
+  return sumsq_impl<float>(d_x, n, h_out, d_ws, ws_bytes, stream);
+}
+extern "C" int ndmps_sumsq_f64(const double* d_x, int64_t n, double* h_out, void* d_ws, int64_t ws_bytes,
+                               ndmps_stream_t stream) {
+  return sumsq_impl<double>(d_x, n, h_out, d_ws, ws_bytes, stream);
 }
 
 extern "C" int ndmps_minmax_f32(const float* d_x, int64_t n, float* h_min, float* h_max, void* d_ws,
@@ -365,16 +417,74 @@ extern "C" int ndmps_minmax_collect(int count, const double* d_partial, float* h
 extern "C" int ndmps_scale_f32(float* d_x, int64_t n, double factor, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_x && n >= 0, "bad scale argument");
   if (n == 0) return NDMPS_OK;
-  hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, d_x, n, factor);
+  hipLaunchKernelGGL(scale_kernel<float>, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, d_x, n, factor);
   NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+extern "C" int ndmps_scale_f64(double* d_x, int64_t n, double factor, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x && n >= 0, "bad scale argument");
+  if (n == 0) return NDMPS_OK;
+  hipLaunchKernelGGL(scale_kernel<double>, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, d_x, n, factor);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_minmax_many_f64(int count, const double* const* h_ptrs, const int64_t* h_lens, double* h_out,
+                                     double* h_sumsq, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(count >= 1 && count <= 65535 && h_ptrs && h_lens && h_out, "bad minmax_many argument");
+  if (!d_ws || ws_bytes < ndmps_minmax_many_workspace_bytes(count)) {
+    ndmps::set_error("minmax_many workspace too small");
+    return NDMPS_EWORKSPACE;
+  }
+  for (int i = 0; i < count; ++i) NDMPS_REQUIRE(h_ptrs[i] && h_lens[i] > 0, "tensor %d is empty or NULL", i);
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)d_ws;
+  const double** d_ptrs = (const double**)base;
+  int64_t* d_lens = (int64_t*)(base + ndmps::round_up((int64_t)count * 8, 256));
+  double* partial = (double*)((char*)d_lens + ndmps::round_up((int64_t)count * 8, 256));
+  NDMPS_CHECK_HIP(hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(double*) * count, hipMemcpyHostToDevice, s));
+  NDMPS_CHECK_HIP(hipMemcpyAsync(d_lens, h_lens, sizeof(int64_t) * count, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(minmax_many_f64_kernel, dim3(kManySlices, count), dim3(256), 0, s, d_ptrs, d_lens, partial);
+  NDMPS_LAUNCH_CHECK();
+  std::vector<double> host((size_t)count * kManySlices * 3);
+  NDMPS_CHECK_HIP(hipMemcpyAsync(host.data(), partial, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < count; ++i) {
+    double lo = DBL_MAX, hi = -DBL_MAX, ss = 0.0;
+    for (int j = 0; j < kManySlices; ++j) {
+      const double* o = &host[3 * ((size_t)i * kManySlices + j)];
+      lo = std::min(lo, o[0]);
+      hi = std::max(hi, o[1]);
+      ss += o[2];
+    }
+    h_out[2 * i] = lo;
+    h_out[2 * i + 1] = hi;
+    if (h_sumsq) h_sumsq[i] = ss;
+  }
   return NDMPS_OK;
 }
 
 extern "C" int ndmps_dct_basis_f32(float* d_basis, int64_t n, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_basis && n >= 1 && n <= 16384, "bad DCT length %lld", (long long)n);
-  hipLaunchKernelGGL(dct_basis_kernel, dim3(stream_grid(n * n)), dim3(256), 0, (hipStream_t)stream, d_basis, n);
+  hipLaunchKernelGGL(dct_basis_kernel<float>, dim3(stream_grid(n * n)), dim3(256), 0, (hipStream_t)stream, d_basis, n);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
+}
+extern "C" int ndmps_dct_basis_f64(double* d_basis, int64_t n, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_basis && n >= 1 && n <= 16384, "bad DCT length %lld", (long long)n);
+  hipLaunchKernelGGL(dct_basis_kernel<double>, dim3(stream_grid(n * n)), dim3(256), 0, (hipStream_t)stream, d_basis, n);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+extern "C" int ndmps_dct_last_f64(const double* d_x, double* d_y, int64_t rows, int64_t n, const double* d_basis,
+                                  ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x != d_y, "DCT is out of place");
+  return ndmps_dgemm(0, 0, rows, n, n, d_x, n, d_basis, n, d_y, n, stream);
+}
+extern "C" int ndmps_idct_last_f64(const double* d_y, double* d_x, int64_t rows, int64_t n, const double* d_basis,
+                                   ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x != d_y, "IDCT is out of place");
+  return ndmps_dgemm(0, 1, rows, n, n, d_y, n, d_basis, n, d_x, n, stream);
 }
 
 extern "C" int ndmps_dct_last_f32(const float* d_x, float* d_y, int64_t rows, int64_t n,
@@ -419,6 +529,40 @@ extern "C" int ndmps_dequantize_f32(const void* d_q, int64_t n, float lo, float 
   else
     hipLaunchKernelGGL(dequantize_kernel<uint16_t>, dim3(stream_grid(n)), dim3(256), 0, s, (const uint16_t*)d_q,
                        n, (double)lo, span, 65535.0, d_x);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_quantize_f64(const double* d_x, int64_t n, double lo, double hi, int bits, void* d_q,
+                                  ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x && d_q && n >= 0, "bad quantize argument");
+  NDMPS_REQUIRE(bits == 8 || bits == 16, "bits=%d not supported (8 or 16)", bits);
+  if (n == 0) return NDMPS_OK;
+  const double span = hi - lo;
+  hipStream_t s = (hipStream_t)stream;
+  if (bits == 8)
+    hipLaunchKernelGGL((quantize_kernel<uint8_t, double>), dim3(stream_grid(n)), dim3(256), 0, s, d_x, n, lo, span, 255.0,
+                       (uint8_t*)d_q);
+  else
+    hipLaunchKernelGGL((quantize_kernel<uint16_t, double>), dim3(stream_grid(n)), dim3(256), 0, s, d_x, n, lo, span,
+                       65535.0, (uint16_t*)d_q);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+extern "C" int ndmps_dequantize_f64(const void* d_q, int64_t n, double lo, double hi, int bits, double* d_x,
+                                    ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_x && d_q && n >= 0, "bad dequantize argument");
+  NDMPS_REQUIRE(bits == 8 || bits == 16, "bits=%d not supported (8 or 16)", bits);
+  if (n == 0) return NDMPS_OK;
+  const double span = hi - lo;
+  hipStream_t s = (hipStream_t)stream;
+  if (bits == 8)
+    hipLaunchKernelGGL((dequantize_kernel<uint8_t, double>), dim3(stream_grid(n)), dim3(256), 0, s, (const uint8_t*)d_q, n,
+                       lo, span, 255.0, d_x);
+  else
+    hipLaunchKernelGGL((dequantize_kernel<uint16_t, double>), dim3(stream_grid(n)), dim3(256), 0, s, (const uint16_t*)d_q,
+                       n, lo, span, 65535.0, d_x);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }

@@ -25,19 +25,23 @@
 namespace {
 
 constexpr double kCutoffFloor = 1e-6;
+// fp64 storage: the Gram route resolves singular values down to ~sqrt(eps) s_0
+constexpr double kCutoffFloorF64 = 1e-8;
+template <typename T>
+constexpr double cutoff_floor() { return sizeof(T) == 8 ? kCutoffFloorF64 : kCutoffFloor; }
 // Jacobi convergence threshold of the sweep's eigenproblems, relative to the largest eigenvalue.
 // The data is fp32: off-diagonal couplings below 1e-13 lambda_0 move the kept subspace by less than
 // fp32 rounding even inside a noise-floor cluster (gaps ~1e-9 lambda_0); override for experiments with
 // NDMPS_SWEEP_EIG_TOL.
 constexpr double kSweepEigTol = 1e-13;
 
-inline double sweep_eig_tol() {
+inline double sweep_eig_tol(bool f64_storage = false) {
   const char* e = getenv("NDMPS_SWEEP_EIG_TOL");
   if (e) {
     const double v = atof(e);
     if (v >= 1e-16 && v <= 1e-6) return v;
   }
-  return kSweepEigTol;
+  return f64_storage ? 1e-15 : kSweepEigTol;  // fp64 data: iterate down to the rounding of the Gram matrix
 }
 
 using ndmps::arena_bytes;
@@ -52,7 +56,7 @@ inline int grid1d(int64_t n) {
 template <typename T = float>
 __global__ void __launch_bounds__(256) f32_to_f64_kernel(const T* __restrict__ x, int64_t n, double* y) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    y[i] = (double)(float)x[i];
+    y[i] = ndmps::to_f64(x[i]);
 }
 
 // core (k x n) fp32 <- first k columns of V (n x n fp64), transposed
@@ -62,7 +66,7 @@ core_from_vectors_kernel(const double* __restrict__ V, int64_t n, int64_t k, T* 
   const int64_t total = k * n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t i = e / n, c = e % n;
-    core[e] = (T)(float)V[c * n + i];
+    core[e] = ndmps::from_f64<T>(V[c * n + i]);
   }
 }
 
@@ -75,7 +79,7 @@ scale_cols_to_f32_kernel(const double* __restrict__ M, int64_t rows, int64_t ldm
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t r = e / k, c = e % k;
     const double sg = sigma[c];
-    out[e] = (T)(float)(sg > 0.0 ? M[r * ldm + c] * pow(sg, power) : 0.0);
+    out[e] = ndmps::from_f64<T>(sg > 0.0 ? M[r * ldm + c] * pow(sg, power) : 0.0);
   }
 }
 
@@ -88,7 +92,7 @@ scale_rows_to_f32_kernel(const double* __restrict__ M, int64_t k, int64_t n, con
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
   {
     const double sg = sigma[e / n];
-    out[e] = (T)(float)(sg > 0.0 ? M[e] * pow(sg, power) : 0.0);
+    out[e] = ndmps::from_f64<T>(sg > 0.0 ? M[e] * pow(sg, power) : 0.0);
   }
 }
 
@@ -116,7 +120,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) f32_to_f64_batched_kernel(BatchOps ops, int64_t n, double* __restrict__ y, int64_t y_stride) {
   const T* x = static_cast<const T*>(ops.in[blockIdx.y]);
   double* yb = y + (int64_t)blockIdx.y * y_stride;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) yb[i] = (double)(float)x[i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) yb[i] = ndmps::to_f64(x[i]);
 }
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -126,7 +130,7 @@ core_from_vectors_batched_kernel(const double* __restrict__ V, int64_t v_stride,
   const int64_t total = k * n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t i = e / n, c = e % n;
-    core[e] = (T)(float)Vb[c * n + i];
+    core[e] = ndmps::from_f64<T>(Vb[c * n + i]);
   }
 }
 __global__ void __launch_bounds__(256)
@@ -146,7 +150,7 @@ scale_cols_to_f32_batched_kernel(const double* __restrict__ M, int64_t m_stride,
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t r = e / k, c = e % k;
     const double sg = sb[c];
-    out[e] = (T)(float)(sg > 0.0 ? Mb[r * ldm + c] * pow(sg, power) : 0.0);
+    out[e] = ndmps::from_f64<T>(sg > 0.0 ? Mb[r * ldm + c] * pow(sg, power) : 0.0);
   }
 }
 template <typename T>
@@ -159,7 +163,7 @@ scale_rows_to_f32_batched_kernel(const double* __restrict__ M, int64_t m_stride,
   const int64_t total = k * n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const double sg = sb[e / n];
-    out[e] = (T)(float)(sg > 0.0 ? Mb[e] * pow(sg, power) : 0.0);
+    out[e] = ndmps::from_f64<T>(sg > 0.0 ? Mb[e] * pow(sg, power) : 0.0);
   }
 }
 
@@ -244,7 +248,7 @@ merge_basis_kernel(const double* __restrict__ Wr, int64_t stride_w, int ldw, con
     double acc = 0.0;
     for (int q = 0; q < kr; ++q) acc = fma(Wb[(int64_t)c * ldw + q], Vb[(int64_t)(a * kr + q) * n + pp], acc);
     Ob[(int64_t)row * ldw + pp] = acc;
-    if (O32) O32[(int64_t)row * kh + pp] = (T)(float)acc;
+    if (O32) O32[(int64_t)row * kh + pp] = ndmps::from_f64<T>(acc);
   }
 }
 
@@ -298,9 +302,9 @@ int merge_start(int L, const int64_t* dims, int64_t numel, int64_t max_bond) {
 }
 
 // keep s_k > cutoff * s_0 (at least one), at most max_bond
-int64_t kept_rank(const std::vector<double>& sigma, double cutoff, int64_t max_bond) {
+int64_t kept_rank(const std::vector<double>& sigma, double cutoff, int64_t max_bond, double floor = kCutoffFloor) {
   const int64_t n = (int64_t)sigma.size();
-  const double c = std::max(cutoff, kCutoffFloor);
+  const double c = std::max(cutoff, floor);
   int64_t k = 0;
   for (int64_t i = 0; i < n; ++i) k += sigma[i] > c * sigma[0];
   k = std::max<int64_t>(k, 1);
@@ -356,7 +360,7 @@ struct SweepLayout {
   int64_t workspace = 0;      // for the batch size it was computed for
 };
 
-int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepLayout& out) {
+int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepLayout& out, int elem_bytes = 4) {
   NDMPS_REQUIRE(L >= 1 && L <= 64, "L=%d outside [1, 64]", L);
   NDMPS_REQUIRE(batch >= 1 && batch <= 4096, "batch=%d outside [1, 4096]", batch);
   out.numel = 1;
@@ -403,7 +407,7 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
   out.spec_stride = max_bond > 0 ? std::min<int64_t>(max_bond, out.small_max) : 0;
   const int64_t sq = out.small_max * out.small_max;
   int64_t used = 0;
-  used = arena_bytes(used, 4, (int64_t)batch * out.numel);              // second carry buffer per volume
+  used = arena_bytes(used, elem_bytes, (int64_t)batch * out.numel);     // second carry buffer per volume
   used = arena_bytes(used, 8, (int64_t)batch * sq);                     // G
   used = arena_bytes(used, 8, (int64_t)batch * sq);                     // V / U
   used = arena_bytes(used, 8, (int64_t)batch * out.small_max);          // w
@@ -416,7 +420,7 @@ int sweep_layout(int L, const int64_t* dims, int64_t max_bond, int batch, SweepL
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_n);      // T = Graw B
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_w);      // accumulated basis W (ping)
   used = arena_bytes(used, 8, (int64_t)batch * out.merge_n * out.merge_w);      // (pong)
-  used = arena_bytes(used, 4, (int64_t)batch * out.merge_n * out.merge_w);      // fp32 / bf16 copy for the projection
+  used = arena_bytes(used, elem_bytes, (int64_t)batch * out.merge_n * out.merge_w);  // copy in the storage type for the projection
   out.transpose_bytes = ndmps_gemm_bf16_workspace_bytes(0, std::max<int64_t>(out.merge_w, 1), std::max<int64_t>(out.merge_n, 1));
   used = arena_bytes(used, 1, out.transpose_bytes);
   used = arena_bytes(used, 4, (int64_t)2 * L * batch);                          // device ranks, status per site
@@ -448,6 +452,13 @@ extern "C" int64_t ndmps_tt_sweep_batched_workspace_bytes(int batch, int L, cons
   if (!h_dims || sweep_layout(L, h_dims, max_bond, batch, lay) != NDMPS_OK) return -1;
   return lay.workspace;
 }
+// the same for fp64 storage (ndmps_tt_sweep_batched_f64): carried matrices of 8-byte elements
+extern "C" int64_t ndmps_tt_sweep_batched_workspace_bytes_f64(int batch, int L, const int64_t* h_dims,
+                                                              int64_t max_bond) {
+  SweepLayout lay;
+  if (!h_dims || sweep_layout(L, h_dims, max_bond, batch, lay, 8) != NDMPS_OK) return -1;
+  return lay.workspace;
+}
 
 // All volumes of the batch have the same site dims; they advance through the sites in lockstep
 // so that every site's eigenproblems are solved by ONE batched Jacobi (its sequential depth is
@@ -460,6 +471,17 @@ inline int gram_T(const float* A, int64_t m, int64_t n, int64_t lda, double* G, 
 inline int gram_T(const __bf16* A, int64_t m, int64_t n, int64_t lda, double* G, void* ws, int64_t wsb, hipStream_t s) {
   return ndmps_gram_bf16(A, m, n, lda, G, ws, wsb, s);
 }
+inline int gram_T(const double* A, int64_t m, int64_t n, int64_t lda, double* G, void* ws, int64_t wsb, hipStream_t s) {
+  return ndmps_gram_f64(A, m, n, lda, G, ws, wsb, s);
+}
+inline int64_t gram_need(const float*, int64_t m, int64_t n) { return ndmps_gram_workspace_bytes(m, n); }
+inline int64_t gram_need(const __bf16*, int64_t m, int64_t n) { return ndmps_gram_workspace_bytes(m, n); }
+inline int64_t gram_need(const double*, int64_t m, int64_t n) { return ndmps_gram_f64_workspace_bytes(m, n); }
+// the group-wide Gram launch (LDS-staged fp32 panels) exists for fp32 / bf16 storage only
+template <typename T>
+inline int64_t gram_batched_need(int batch, int64_t m, int64_t n) {
+  return sizeof(T) == 8 ? 0 : ndmps_gram_batched_workspace_bytes(batch, m, n);
+}
 // one launch for the Gram matrices of a lockstep group (same shape; n >= 128, m >= 256)
 inline int gram_batched_T(int batch, const float* const* A, int64_t m, int64_t n, double* G, int64_t stride, void* ws,
                           int64_t wsb, hipStream_t s) {
@@ -468,6 +490,15 @@ inline int gram_batched_T(int batch, const float* const* A, int64_t m, int64_t n
 inline int gram_batched_T(int batch, const __bf16* const* A, int64_t m, int64_t n, double* G, int64_t stride, void* ws,
                           int64_t wsb, hipStream_t s) {
   return ndmps_gram_batched_bf16(batch, (const void* const*)A, m, n, n, G, stride, ws, wsb, s);
+}
+inline int gram_batched_T(int, const double* const*, int64_t, int64_t, double*, int64_t, void*, int64_t, hipStream_t) {
+  ndmps::set_error("internal: no group-wide Gram launch for fp64 storage");
+  return NDMPS_EINVAL;
+}
+inline int gram_batched_src(int, const double* const*, int64_t, int64_t, const SweepSource&, double*, int64_t, void*,
+                            int64_t, hipStream_t) {
+  ndmps::set_error("the fused reshape stage is fp32 only");
+  return NDMPS_EINVAL;
 }
 inline int gram_batched_src(int batch, const float* const* vol, int64_t m, int64_t n, const SweepSource& src, double* G,
                             int64_t stride, void* ws, int64_t wsb, hipStream_t s) {
@@ -488,7 +519,28 @@ inline int gemm_T(int transB, int64_t m, int64_t n, int64_t k, const __bf16* A, 
   return ndmps_gemm_bf16(transB, m, n, k, A, k, B, ldb, C, n, tws, tws_bytes, s);
 }
 
-// products of a whole lockstep group in one launch (fp32 storage; bf16 storage goes volume by volume)
+inline int gemm_T(int transB, int64_t m, int64_t n, int64_t k, const double* A, const double* B, int64_t ldb, double* C,
+                  void*, int64_t, hipStream_t s) {
+  return ndmps_dgemm(0, transB, m, n, k, A, k, B, ldb, C, n, s);
+}
+
+// general product with explicit leading dimensions (fp32 / fp64)
+inline int gemm_any(int tA, int tB, int64_t m, int64_t n, int64_t k, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, hipStream_t s) {
+  return ndmps_sgemm(tA, tB, m, n, k, A, lda, B, ldb, C, ldc, s);
+}
+inline int gemm_any(int tA, int tB, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                    int64_t ldb, double* C, int64_t ldc, hipStream_t s) {
+  return ndmps_dgemm(tA, tB, m, n, k, A, lda, B, ldb, C, ldc, s);
+}
+
+// products of a whole lockstep group in one launch (fp32 / fp64 storage; bf16 storage goes volume by volume)
+inline bool gemm_batched_T(int batch, int transB, int64_t m, int64_t n, int64_t k, double* const* A, double* const* B,
+                           int64_t ldb, double* const* C, hipStream_t s, int* rc) {
+  if (batch > ndmps_gemm_batched_max()) return false;
+  *rc = ndmps_dgemm_batched(batch, 0, transB, m, n, k, (const double* const*)A, k, (const double* const*)B, ldb, C, n, s);
+  return true;
+}
 inline bool gemm_batched_T(int batch, int transB, int64_t m, int64_t n, int64_t k, float* const* A, float* const* B,
                            int64_t ldb, float* const* C, hipStream_t s, int* rc) {
   if (batch > ndmps_gemm_batched_max()) return false;
@@ -506,6 +558,14 @@ inline int gram_src(const float* vol, int64_t m, int64_t n, const SweepSource& s
 }
 inline int gram_src(const __bf16*, int64_t, int64_t, const SweepSource&, double*, void*, int64_t, hipStream_t) {
   ndmps::set_error("the fused reshape stage is fp32 only");
+  return NDMPS_EINVAL;
+}
+inline int gram_src(const double*, int64_t, int64_t, const SweepSource&, double*, void*, int64_t, hipStream_t) {
+  ndmps::set_error("the fused reshape stage is fp32 only");
+  return NDMPS_EINVAL;
+}
+inline int project_src(const double*, int64_t, int64_t, int64_t, const SweepSource&, const double*, double*, double*,
+                       hipStream_t) {
   return NDMPS_EINVAL;
 }
 inline int project_src(const float* vol, int64_t m, int64_t k, int64_t n, const SweepSource& src, const float* W,
@@ -537,7 +597,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
   NDMPS_REQUIRE(h_dense && h_dims && h_cores && h_core_offsets && h_bonds_out, "NULL sweep argument");
   NDMPS_REQUIRE(cutoff >= 0.0, "cutoff must be non-negative");
   SweepLayout lay;
-  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, batch, lay));
+  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, batch, lay, sizeof(T) == 8 ? 8 : 4));
   if (d_ws == nullptr || ws_bytes < lay.workspace) {
     ndmps::set_error("sweep workspace too small: %lld < %lld", (long long)ws_bytes, (long long)lay.workspace);
     return NDMPS_EWORKSPACE;
@@ -604,7 +664,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       // no host round trip: eigenvalues -> rank (device) -> k_b eigenvectors, the other columns up to the cap zero
       NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
                                             ev_ws_bytes, s));
-      NDMPS_TRY(ndmps_syevd_topk_vectors_auto_f64(batch, eig_n.data(), k_cap, std::max(cutoff, kCutoffFloor),
+      NDMPS_TRY(ndmps_syevd_topk_vectors_auto_f64(batch, eig_n.data(), k_cap, std::max(cutoff, cutoff_floor<T>()),
                                                   d_ranks + (int64_t)i * batch, d_spec + (int64_t)i * batch * lay.spec_stride,
                                                   lay.spec_stride, d_status + (int64_t)i * batch, ev_ws, ev_ws_bytes, s));
       for (int b = 0; b < batch; ++b) kept[b] = k_cap;
@@ -614,7 +674,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
                                             ev_ws_bytes, s));
     else
-      NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(),
+      NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(sizeof(T) == 8),
                                                ev_ws, ev_ws_bytes, &sweeps, s));
     NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
                                    hipMemcpyDeviceToHost, s));
@@ -624,7 +684,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       std::vector<double> sv(host_w.begin() + (int64_t)b * lay.small_max,
                              host_w.begin() + (int64_t)b * lay.small_max + small);
       for (auto& x : sv) x = sqrt(std::max(x, 0.0));
-      kept[b] = kept_rank(sv, cutoff, max_bond);
+      kept[b] = kept_rank(sv, cutoff, max_bond, cutoff_floor<T>());
       if (h_spectra && h_spec_offsets) {
         // the layout reserves min(m, d_i max_bond_{i+1}) values for the bond; a merged site may be larger
         const int64_t room = h_spec_offsets[i + 1] - h_spec_offsets[i];
@@ -665,7 +725,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     const int i0 = lay.merge_from;
     const int64_t n0 = lay.merge_n, ldw = lay.merge_w, m0 = lay.numel / n0;
     const int64_t stride_top = n0 * n0, stride_w = n0 * ldw;
-    const int64_t raw_batched = ndmps_gram_batched_workspace_bytes(batch, m0, n0);
+    const int64_t raw_batched = gram_batched_need<T>(batch, m0, n0);
     if (batch > 1 && raw_batched > 0 && raw_batched <= lay.gram_ws) {
       // the whole group in one launch (long slabs: a fraction of the partial tiles, no launch gaps)
       if (src) {
@@ -836,7 +896,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     if (together) {
       const int64_t n = h_dims[i] * chi_r[0];
       m = cur_elems[0] / n;
-      const int64_t need = n <= m ? ndmps_gram_batched_workspace_bytes(batch, m, n) : 0;
+      const int64_t need = n <= m ? gram_batched_need<T>(batch, m, n) : 0;
       together = need > 0 && need <= lay.gram_ws && n * n <= sq;
       if (together) {
         for (int b = 0; b < batch; ++b) eig_n[b] = n;
@@ -872,7 +932,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       eig_n[b] = std::min(m, n);
       double* Gb = G + (int64_t)b * sq;
       if (n <= m) {
-        const int64_t need = ndmps_gram_workspace_bytes(m, n);
+        const int64_t need = gram_need(cur[b], m, n);
         NDMPS_REQUIRE(need <= lay.gram_ws, "internal: Gram workspace bound violated (%lld > %lld)",
                       (long long)need, (long long)lay.gram_ws);
         NDMPS_TRY(gram_T(cur[b], m, n, n, Gb, gram_ws, lay.gram_ws, s));
@@ -1051,6 +1111,20 @@ extern "C" int ndmps_tt_sweep_batched_bf16(int batch, void* const* h_dense, int 
                             h_core_offsets, h_bonds_out, h_spectra, h_spec_offsets, d_ws, ws_bytes, stream);
 }
 
+// fp64 storage, the reference's own element type (core/ndmps.py:56): volume / site-order tensor, carried matrices and
+// cores are fp64 in HBM, every product runs on the fp64 MFMA (ndmps_dgemm), Gram matrices and eigen-decompositions
+// are fp64 as in the other storage types.  Workspace: ndmps_tt_sweep_batched_workspace_bytes_f64; layout offsets
+// (ndmps_tt_layout) are in elements and shared with the other storage types.  The relative cutoff is clamped below
+// at 1e-8 (singular values come from fp64 Gram matrices: sqrt(eps) s_0 is what they resolve).
+extern "C" int ndmps_tt_sweep_batched_f64(int batch, double* const* h_dense, int L, const int64_t* h_dims,
+                                          double cutoff, int64_t max_bond, double* const* h_cores,
+                                          const int64_t* h_core_offsets, int64_t* h_bonds_out,
+                                          double* h_spectra, const int64_t* h_spec_offsets, void* d_ws,
+                                          int64_t ws_bytes, ndmps_stream_t stream) {
+  return sweep_impl<double>(batch, h_dense, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets, h_bonds_out, h_spectra,
+                            h_spec_offsets, d_ws, ws_bytes, stream);
+}
+
 extern "C" int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cutoff,
                                   int64_t max_bond, float* d_cores, const int64_t* h_core_offsets,
                                   int64_t* h_bonds_out, double* h_spectra, const int64_t* h_spec_offsets,
@@ -1086,11 +1160,11 @@ extern "C" int64_t ndmps_compress_bond_workspace_bytes(int64_t chi_l, int64_t d1
   used = arena_bytes(used, 8, chi);      // w2
   used = arena_bytes(used, 8, chi);      // wh
   used = arena_bytes(used, 8, chi);      // sigma
-  used = arena_bytes(used, 4, c2);       // A1 fp32
-  used = arena_bytes(used, 4, c2);       // B2 fp32
+  used = arena_bytes(used, 8, c2);       // A1 in the storage type
+  used = arena_bytes(used, 8, c2);       // B2 in the storage type
   used = arena_bytes(used, 8, chi * n2); // t2 in fp64
   used = arena_bytes(used, 1, ndmps_syevj_workspace_bytes(chi));
-  used = arena_bytes(used, 1, ndmps_gram_workspace_bytes(m1, chi));
+  used = arena_bytes(used, 1, std::max(ndmps_gram_workspace_bytes(m1, chi), ndmps_gram_f64_workspace_bytes(m1, chi)));
   return ndmps::round_up(used, 256) + 256;
 }
 
@@ -1098,10 +1172,11 @@ extern "C" int64_t ndmps_compress_bond_workspace_bytes(int64_t chi_l, int64_t d1
 // Q factors: with G1 = T1^T T1, G2 = T2 T2^T = W D W^T, Lt = W D^(1/2) and H = Lt^T G1 Lt
 // = V diag(s^2) V^T (the s are the singular values of P), the absorb-"both" cores are
 //   T1' = T1 (Lt V_k) s_k^(-1/2),   T2' = s_k^(-3/2) (G1 Lt V_k)^T T2 .
-extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int64_t chi_l, int64_t d1,
-                                       int64_t chi, int64_t d2, int64_t chi_r, double cutoff,
-                                       int64_t max_bond, float* d_new1, float* d_new2, int64_t* h_new_chi,
-                                       double* h_s, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+namespace {
+template <typename T>
+int compress_bond_impl(const T* d_t1, const T* d_t2, int64_t chi_l, int64_t d1, int64_t chi, int64_t d2, int64_t chi_r,
+                       double cutoff, int64_t max_bond, T* d_new1, T* d_new2, int64_t* h_new_chi, double* h_s, void* d_ws,
+                       int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_t1 && d_t2 && d_new1 && d_new2 && h_new_chi, "NULL compress_bond argument");
   NDMPS_REQUIRE(chi_l > 0 && d1 > 0 && chi > 0 && d2 > 0 && chi_r > 0, "bad core shape");
   NDMPS_REQUIRE(cutoff >= 0.0, "cutoff must be non-negative");
@@ -1124,20 +1199,20 @@ extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int
   double* w2 = ar.take<double>(chi);
   double* wh = ar.take<double>(chi);
   double* sig = ar.take<double>(chi);
-  float* A1 = ar.take<float>(c2);
-  float* B2 = ar.take<float>(c2);
+  T* A1 = reinterpret_cast<T*>(ar.take<double>(c2));
+  T* B2 = reinterpret_cast<T*>(ar.take<double>(c2));
   double* t2d = ar.take<double>(chi * n2);
   const int64_t ev_bytes = ndmps_syevj_workspace_bytes(chi);
   char* ev_ws = ar.take<char>(ev_bytes);
-  const int64_t gram_bytes = ndmps_gram_workspace_bytes(m1, chi);
+  const int64_t gram_bytes = std::max(ndmps_gram_workspace_bytes(m1, chi), ndmps_gram_f64_workspace_bytes(m1, chi));
   char* gram_ws = ar.take<char>(gram_bytes);
   NDMPS_REQUIRE(G1 && G2 && Lt && tmp && H && V && P1 && P2 && w2 && wh && sig && A1 && B2 && t2d && ev_ws &&
                     gram_ws,
                 "workspace carve failed");
 
   int sweeps = 0;
-  NDMPS_TRY(ndmps_gram_f32(d_t1, m1, chi, chi, G1, gram_ws, gram_bytes, s));
-  hipLaunchKernelGGL(f32_to_f64_kernel<float>, dim3(grid1d(chi * n2)), dim3(256), 0, s, d_t2, chi * n2, t2d);
+  NDMPS_TRY(gram_T(d_t1, m1, chi, chi, G1, gram_ws, gram_bytes, s));
+  hipLaunchKernelGGL(f32_to_f64_kernel<T>, dim3(grid1d(chi * n2)), dim3(256), 0, s, d_t2, chi * n2, t2d);
   NDMPS_LAUNCH_CHECK();
   NDMPS_TRY(ndmps_dgemm(0, 1, chi, chi, n2, t2d, n2, t2d, n2, G2, chi, s));
   NDMPS_TRY(ndmps_syevj_f64(G2, chi, Lt, w2, ev_ws, ev_bytes, &sweeps, s));
@@ -1151,7 +1226,7 @@ extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int
   NDMPS_CHECK_HIP(hipMemcpyAsync(sv.data(), wh, chi * sizeof(double), hipMemcpyDeviceToHost, s));
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   for (auto& x : sv) x = sqrt(std::max(x, 0.0));  // eigenvalues of H are s^2
-  const int64_t k = kept_rank(sv, cutoff, max_bond);
+  const int64_t k = kept_rank(sv, cutoff, max_bond, cutoff_floor<T>());
   if (h_s) memcpy(h_s, sv.data(), chi * sizeof(double));
   *h_new_chi = k;
 
@@ -1159,13 +1234,30 @@ extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int
   NDMPS_LAUNCH_CHECK();
   NDMPS_TRY(ndmps_dgemm(0, 0, chi, k, chi, Lt, chi, V, chi, P1, k, s));
   NDMPS_TRY(ndmps_dgemm(0, 0, chi, k, chi, tmp, chi, V, chi, P2, k, s));
-  hipLaunchKernelGGL(scale_cols_to_f32_kernel<float>, dim3(grid1d(chi * k)), dim3(256), 0, s, P1, chi, k, k, sig, -0.5, A1);
-  hipLaunchKernelGGL(scale_cols_to_f32_kernel<float>, dim3(grid1d(chi * k)), dim3(256), 0, s, P2, chi, k, k, sig, -1.5, B2);
+  hipLaunchKernelGGL(scale_cols_to_f32_kernel<T>, dim3(grid1d(chi * k)), dim3(256), 0, s, P1, chi, k, k, sig, -0.5, A1);
+  hipLaunchKernelGGL(scale_cols_to_f32_kernel<T>, dim3(grid1d(chi * k)), dim3(256), 0, s, P2, chi, k, k, sig, -1.5, B2);
   NDMPS_LAUNCH_CHECK();
-  NDMPS_TRY(ndmps_sgemm(0, 0, m1, k, chi, d_t1, chi, A1, k, d_new1, k, s));      // (chi_l d1, k)
-  NDMPS_TRY(ndmps_sgemm(1, 0, k, n2, chi, B2, k, d_t2, n2, d_new2, n2, s));      // (k, d2 chi_r)
+  NDMPS_TRY(gemm_any(0, 0, m1, k, chi, d_t1, chi, A1, k, d_new1, k, s));      // (chi_l d1, k)
+  NDMPS_TRY(gemm_any(1, 0, k, n2, chi, B2, k, d_t2, n2, d_new2, n2, s));      // (k, d2 chi_r)
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   return NDMPS_OK;
+}
+}  // namespace
+
+extern "C" int ndmps_compress_bond_f32(const float* d_t1, const float* d_t2, int64_t chi_l, int64_t d1,
+                                       int64_t chi, int64_t d2, int64_t chi_r, double cutoff,
+                                       int64_t max_bond, float* d_new1, float* d_new2, int64_t* h_new_chi,
+                                       double* h_s, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  return compress_bond_impl<float>(d_t1, d_t2, chi_l, d1, chi, d2, chi_r, cutoff, max_bond, d_new1, d_new2, h_new_chi, h_s,
+                                   d_ws, ws_bytes, stream);
+}
+// fp64 cores (same workspace query)
+extern "C" int ndmps_compress_bond_f64(const double* d_t1, const double* d_t2, int64_t chi_l, int64_t d1,
+                                       int64_t chi, int64_t d2, int64_t chi_r, double cutoff,
+                                       int64_t max_bond, double* d_new1, double* d_new2, int64_t* h_new_chi,
+                                       double* h_s, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  return compress_bond_impl<double>(d_t1, d_t2, chi_l, d1, chi, d2, chi_r, cutoff, max_bond, d_new1, d_new2, h_new_chi, h_s,
+                                    d_ws, ws_bytes, stream);
 }
 
 // =================================================================== chain contraction
@@ -1206,14 +1298,22 @@ ChainPlan chain_plan(int L, const int64_t* dims, const int64_t* bonds) {
 }
 }  // namespace
 
-extern "C" int64_t ndmps_chain_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds) {
+namespace {
+int64_t chain_workspace(int L, const int64_t* h_dims, const int64_t* h_bonds, int64_t elem_bytes) {
   if (L < 1 || !h_dims || !h_bonds) return 0;
   const ChainPlan p = chain_plan(L, h_dims, h_bonds);
   // + room for the transposed right operand of a bf16 product (a core or a tail matrix)
   int64_t biggest_b = p.tail_elems;
   for (int i = 0; i < L; ++i) biggest_b = std::max(biggest_b, h_bonds[i] * h_dims[i] * h_bonds[i + 1]);
-  return (ndmps::round_up(p.left_elems, 64) + 2 * ndmps::round_up(p.tail_elems, 64)) * (int64_t)sizeof(float) +
+  return (ndmps::round_up(p.left_elems, 64) + 2 * ndmps::round_up(p.tail_elems, 64)) * elem_bytes +
          ndmps::round_up(biggest_b * 2, 256) + 1024;
+}
+}  // namespace
+extern "C" int64_t ndmps_chain_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds) {
+  return chain_workspace(L, h_dims, h_bonds, sizeof(float));
+}
+extern "C" int64_t ndmps_chain_workspace_bytes_f64(int L, const int64_t* h_dims, const int64_t* h_bonds) {
+  return chain_workspace(L, h_dims, h_bonds, sizeof(double));
 }
 
 namespace {
@@ -1241,6 +1341,10 @@ inline int final_product(int64_t rows, int64_t n_tail, int64_t k, const float* l
   return ndmps_sgemm_indexed(rows, n_tail, k, left, k, nullptr, nullptr, 0, spare, n_tail, d_out, 0, sc->row_off,
                              sc->col_off, s);
 }
+inline int final_product(int64_t rows, int64_t n_tail, int64_t k, const double* left, const double* R, double*,
+                         double* d_out, const ChainScatter*, void* tws, int64_t tws_bytes, hipStream_t s) {
+  return gemm_T(0, rows, n_tail, k, left, R, n_tail, d_out, tws, tws_bytes, s);
+}
 inline int final_product(int64_t rows, int64_t n_tail, int64_t k, const __bf16* left, const __bf16* R, __bf16*,
                          __bf16* d_out, const ChainScatter*, void* tws, int64_t tws_bytes, hipStream_t s) {
   return gemm_T(0, rows, n_tail, k, left, R, n_tail, d_out, tws, tws_bytes, s);
@@ -1267,7 +1371,7 @@ int chain_impl(int L, const int64_t* h_dims, const int64_t* h_bonds, const T* co
                     (long long)h_bonds[i + 1], (long long)left, (long long)(numel / left));
     }
   }
-  const int64_t need = ndmps_chain_workspace_bytes(L, h_dims, h_bonds);
+  const int64_t need = chain_workspace(L, h_dims, h_bonds, sizeof(T) == 8 ? 8 : 4);
   if (!d_ws || ws_bytes < need) {
     ndmps::set_error("chain workspace too small: %lld < %lld", (long long)ws_bytes, (long long)need);
     return NDMPS_EWORKSPACE;
@@ -1518,6 +1622,13 @@ extern "C" int ndmps_chain_contract_bf16(int L, const int64_t* h_dims, const int
   return chain_impl<__bf16>(L, h_dims, h_bonds, (const __bf16* const*)h_cores, (__bf16*)d_dense, d_ws, ws_bytes, stream);
 }
 
+// fp64 cores: every product on the fp64 MFMA (workspace: ndmps_chain_workspace_bytes_f64)
+extern "C" int ndmps_chain_contract_f64(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                                        const double* const* h_cores, double* d_dense, void* d_ws,
+                                        int64_t ws_bytes, ndmps_stream_t stream) {
+  return chain_impl<double>(L, h_dims, h_bonds, h_cores, d_dense, d_ws, ws_bytes, stream);
+}
+
 // =================================================================== overlap
 extern "C" int64_t ndmps_overlap_workspace_bytes(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
                                                  const int64_t* h_bonds_b) {
@@ -1538,10 +1649,11 @@ extern "C" int64_t ndmps_overlap_workspace_bytes(int L, const int64_t* h_dims, c
   return ndmps::round_up(used, 256) + 256;
 }
 
-extern "C" int ndmps_overlap_f32(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
-                                 const float* const* h_cores_a, const int64_t* h_bonds_b,
-                                 const float* const* h_cores_b, double* h_out, void* d_ws,
-                                 int64_t ws_bytes, ndmps_stream_t stream) {
+namespace {
+template <typename T>
+int overlap_impl(int L, const int64_t* h_dims, const int64_t* h_bonds_a, const T* const* h_cores_a,
+                 const int64_t* h_bonds_b, const T* const* h_cores_b, double* h_out, void* d_ws, int64_t ws_bytes,
+                 ndmps_stream_t stream) {
   NDMPS_REQUIRE(L >= 1 && h_dims && h_bonds_a && h_bonds_b && h_cores_a && h_cores_b && h_out,
                 "bad overlap argument");
   const int64_t need = ndmps_overlap_workspace_bytes(L, h_dims, h_bonds_a, h_bonds_b);
@@ -1572,8 +1684,8 @@ extern "C" int ndmps_overlap_f32(int L, const int64_t* h_dims, const int64_t* h_
     const int64_t ca = h_bonds_a[i], ca2 = h_bonds_a[i + 1];
     const int64_t cb = h_bonds_b[i], cb2 = h_bonds_b[i + 1];
     const int64_t d = h_dims[i];
-    hipLaunchKernelGGL(f32_to_f64_kernel<float>, dim3(grid1d(ca * d * ca2)), dim3(256), 0, s, h_cores_a[i], ca * d * ca2, A);
-    hipLaunchKernelGGL(f32_to_f64_kernel<float>, dim3(grid1d(cb * d * cb2)), dim3(256), 0, s, h_cores_b[i], cb * d * cb2, B);
+    hipLaunchKernelGGL(f32_to_f64_kernel<T>, dim3(grid1d(ca * d * ca2)), dim3(256), 0, s, h_cores_a[i], ca * d * ca2, A);
+    hipLaunchKernelGGL(f32_to_f64_kernel<T>, dim3(grid1d(cb * d * cb2)), dim3(256), 0, s, h_cores_b[i], cb * d * cb2, B);
     NDMPS_LAUNCH_CHECK();
     // X (cb, d ca2) = E^T (cb, ca) A (ca, d ca2)
     NDMPS_TRY(ndmps_dgemm(1, 0, cb, d * ca2, ca, E[cur], cb, A, d * ca2, X, d * ca2, s));
@@ -1584,4 +1696,19 @@ extern "C" int ndmps_overlap_f32(int L, const int64_t* h_dims, const int64_t* h_
   NDMPS_CHECK_HIP(hipMemcpyAsync(h_out, E[cur], sizeof(double), hipMemcpyDeviceToHost, s));
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   return NDMPS_OK;
+}
+}  // namespace
+
+extern "C" int ndmps_overlap_f32(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
+                                 const float* const* h_cores_a, const int64_t* h_bonds_b,
+                                 const float* const* h_cores_b, double* h_out, void* d_ws,
+                                 int64_t ws_bytes, ndmps_stream_t stream) {
+  return overlap_impl<float>(L, h_dims, h_bonds_a, h_cores_a, h_bonds_b, h_cores_b, h_out, d_ws, ws_bytes, stream);
+}
+// fp64 cores (same workspace query)
+extern "C" int ndmps_overlap_f64(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
+                                 const double* const* h_cores_a, const int64_t* h_bonds_b,
+                                 const double* const* h_cores_b, double* h_out, void* d_ws,
+                                 int64_t ws_bytes, ndmps_stream_t stream) {
+  return overlap_impl<double>(L, h_dims, h_bonds_a, h_cores_a, h_bonds_b, h_cores_b, h_out, d_ws, ws_bytes, stream);
 }

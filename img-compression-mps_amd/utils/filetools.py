@@ -32,10 +32,10 @@ def _bits(dtype) -> int:
 
 def _f32(t):
     """fp32 view of a core for the fp32 reduction / quantisation kernels (bf16 cores are a few MB at most:
-    the upcast copy is plumbing, not a data path)."""
+    the upcast copy is plumbing, not a data path).  fp64 cores stay fp64: they have kernels of their own."""
     import torch
 
-    return t if t.dtype == torch.float32 else t.to(torch.float32)
+    return t if t.dtype in (torch.float32, torch.float64) else t.to(torch.float32)
 
 
 def minmax(t):
@@ -44,6 +44,8 @@ def minmax(t):
 
     lib = _lib.load()
     t = _f32(t)
+    if t.dtype == torch.float64:
+        return minmax_many([t])[0]
     ws = torch.empty(lib.ndmps_reduce_workspace_bytes(), dtype=torch.uint8, device=t.device)
     lo, hi = C.c_float(), C.c_float()
     t = t.contiguous()
@@ -58,12 +60,25 @@ def minmax_many(tensors, with_sumsq=False):
     import torch
 
     lib = _lib.load()
+    tensors = list(tensors)
+    if tensors and all(t.dtype == torch.float64 for t in tensors):
+        ts = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+        count = len(ts)
+        nbytes = lib.ndmps_minmax_many_workspace_bytes(count)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=ts[0].device)
+        ptrs = (C.c_void_p * count)(*[t.data_ptr() for t in ts])
+        lens = _lib.i64_array([t.numel() for t in ts])
+        out = (C.c_double * (2 * count))()
+        ss = (C.c_double * count)()
+        _lib.check(lib.ndmps_minmax_many_f64(count, ptrs, lens, out, ss, ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        mm = [(float(out[2 * i]), float(out[2 * i + 1])) for i in range(count)]
+        return (mm, [float(v) for v in ss]) if with_sumsq else mm
     ts = []
     for t in tensors:  # fp32 contiguous tensors (the usual case) pass through without a call
         if t.dtype is torch.float32 and t.is_contiguous():
             ts.append(t)
         else:
-            u = _f32(t)
+            u = t.to(torch.float32)  # mixed lists and bf16 cores: fp32 copies
             ts.append(u if u.is_contiguous() else u.contiguous())
     count = len(ts)
     if count == 0:
@@ -89,18 +104,21 @@ def scale_to_dtype(t, dtype=np.uint8):
     lo, hi = minmax(t)
     # torch has no uint16 arithmetic, but int16 storage has the same bytes
     q = torch.empty(t.shape, dtype=torch.uint8 if bits == 8 else torch.int16, device=t.device)
-    _lib.check(lib.ndmps_quantize_f32(t.data_ptr(), t.numel(), lo, hi, bits, q.data_ptr(), _lib.stream_ptr()))
+    fn = lib.ndmps_quantize_f64 if t.dtype == torch.float64 else lib.ndmps_quantize_f32
+    _lib.check(fn(t.data_ptr(), t.numel(), lo, hi, bits, q.data_ptr(), _lib.stream_ptr()))
     return q
 
 
-def scale_back(q, arr_min, arr_max, dtype=np.uint8):
+def scale_back(q, arr_min, arr_max, dtype=np.uint8, out_dtype=None):
+    """``out_dtype=torch.float64`` dequantises in the reference's own element type."""
     import torch
 
     bits = _bits(dtype)
     lib = _lib.load()
-    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
-    _lib.check(lib.ndmps_dequantize_f32(q.data_ptr(), q.numel(), float(arr_min), float(arr_max), bits,
-                                        out.data_ptr(), _lib.stream_ptr()))
+    f64 = out_dtype == torch.float64
+    out = torch.empty(q.shape, dtype=torch.float64 if f64 else torch.float32, device=q.device)
+    fn = lib.ndmps_dequantize_f64 if f64 else lib.ndmps_dequantize_f32
+    _lib.check(fn(q.data_ptr(), q.numel(), float(arr_min), float(arr_max), bits, out.data_ptr(), _lib.stream_ptr()))
     return out
 
 

@@ -403,6 +403,59 @@ int64_t ndmps_psnr_workspace_bytes(void);
 int ndmps_psnr_f32(const float* d_a, const float* d_b, int64_t n, double* h_out, void* d_ws,
                    int64_t ws_bytes, ndmps_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * fp64 storage -- the reference's own element type (core/ndmps.py:56 `tensor.astype(np.float64)`): volume, carried
+ * matrices and cores are fp64 in HBM and every product runs on the fp64 MFMA, so that the reference's own
+ * tolerances hold (tests/core/test_ndmps.py:35-38 round trip atol 1e-10; :41-44, :63-66 norm rel 1e-12).  Same
+ * argument meaning as the _f32 twins; layout offsets (ndmps_tt_layout) are in elements and shared.  Singular values
+ * come from fp64 Gram matrices: the relative cutoff of the sweep is clamped below at 1e-8 (sqrt(eps) s_0).
+ *   ndmps_gram_f64                  G = A^T A, A fp64                    (core/ndmps.py:74, the SVD of from_dense)
+ *   ndmps_tt_sweep_batched_f64      MatrixProductState.from_dense        (core/ndmps.py:74)
+ *   ndmps_compress_bond_f64         tensor_compress_bond                 (core/ndmps.py:104-106)
+ *   ndmps_chain_contract_f64        mps ^ ...                            (core/ndmps.py:140)
+ *   ndmps_overlap_f64               mps @ mps                            (core/ndmps.py:76,86)
+ *   ndmps_sumsq_f64 / _scale_f64    tensor /= np.linalg.norm(tensor)     (core/ndmps.py:60-61)
+ *   ndmps_minmax_many_f64           boundary_list                        (core/ndmps.py:75,80-82)
+ *   ndmps_dct_basis_f64 / _dct_last_f64 / _idct_last_f64  scipy dct / idct, norm="ortho" (core/ndmps.py:62-63,152-153)
+ *   ndmps_quantize_f64 / _dequantize_f64  scale_to_dtype / scale_back    (utils/filetools.py:20-39)
+ * --------------------------------------------------------------------------------- */
+int64_t ndmps_gram_f64_workspace_bytes(int64_t m, int64_t n);
+int ndmps_gram_f64(const double* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, void* d_ws,
+                   int64_t ws_bytes, ndmps_stream_t stream);
+int64_t ndmps_tt_sweep_batched_workspace_bytes_f64(int batch, int L, const int64_t* h_dims, int64_t max_bond);
+int ndmps_tt_sweep_batched_f64(int batch, double* const* h_dense, int L, const int64_t* h_dims,
+                               double cutoff, int64_t max_bond, double* const* h_cores,
+                               const int64_t* h_core_offsets, int64_t* h_bonds_out, double* h_spectra,
+                               const int64_t* h_spec_offsets, void* d_ws, int64_t ws_bytes,
+                               ndmps_stream_t stream);
+int ndmps_compress_bond_f64(const double* d_t1, const double* d_t2, int64_t chi_l, int64_t d1,
+                            int64_t chi, int64_t d2, int64_t chi_r, double cutoff, int64_t max_bond,
+                            double* d_new1, double* d_new2, int64_t* h_new_chi, double* h_s, void* d_ws,
+                            int64_t ws_bytes, ndmps_stream_t stream);
+int64_t ndmps_chain_workspace_bytes_f64(int L, const int64_t* h_dims, const int64_t* h_bonds);
+int ndmps_chain_contract_f64(int L, const int64_t* h_dims, const int64_t* h_bonds,
+                             const double* const* h_cores, double* d_dense, void* d_ws, int64_t ws_bytes,
+                             ndmps_stream_t stream);
+int ndmps_overlap_f64(int L, const int64_t* h_dims, const int64_t* h_bonds_a,
+                      const double* const* h_cores_a, const int64_t* h_bonds_b,
+                      const double* const* h_cores_b, double* h_out, void* d_ws, int64_t ws_bytes,
+                      ndmps_stream_t stream);
+int ndmps_sumsq_f64(const double* d_x, int64_t n, double* h_out, void* d_ws, int64_t ws_bytes,
+                    ndmps_stream_t stream);
+int ndmps_scale_f64(double* d_x, int64_t n, double factor, ndmps_stream_t stream);
+/* h_out: 2 * count doubles (min, max); h_sumsq may be NULL; workspace: ndmps_minmax_many_workspace_bytes */
+int ndmps_minmax_many_f64(int count, const double* const* h_ptrs, const int64_t* h_lens, double* h_out,
+                          double* h_sumsq, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+int ndmps_dct_basis_f64(double* d_basis, int64_t n, ndmps_stream_t stream);
+int ndmps_dct_last_f64(const double* d_x, double* d_y, int64_t rows, int64_t n, const double* d_basis,
+                       ndmps_stream_t stream);
+int ndmps_idct_last_f64(const double* d_y, double* d_x, int64_t rows, int64_t n, const double* d_basis,
+                        ndmps_stream_t stream);
+int ndmps_quantize_f64(const double* d_x, int64_t n, double lo, double hi, int bits, void* d_q,
+                       ndmps_stream_t stream);
+int ndmps_dequantize_f64(const void* d_q, int64_t n, double lo, double hi, int bits, double* d_x,
+                         ndmps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
