@@ -6,12 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imgcompressionmps_amd import NDMPS
 from oracle.metrics import synthetic_mri
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-x = torch.from_numpy(synthetic_mri((size,) * 3, seed=2025)).cuda()
+# third argument "f64": fp64 storage (the reference's own element type)
+store = torch.float64 if "f64" in sys.argv[2:] else torch.float32
+x = torch.from_numpy(synthetic_mri((size,) * 3, seed=2025)).cuda().to(store)
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    o = NDMPS.from_tensor(x)
+    o = NDMPS.from_tensor(x, dtype=store)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    print(f"exact from_tensor {size}^3: {t1 - t0:.3f} s bonds={o.bond_sizes()} elems={o.number_elements_in_MPS()}", flush=True)
+    exact_bonds = o.bond_sizes()
+    print(f"exact from_tensor {size}^3 ({str(store)[6:]} storage): {t1 - t0:.3f} s bonds={exact_bonds} elems={o.number_elements_in_MPS()}", flush=True)
     r = o.to_tensor(as_torch=True); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"  to_tensor (exact MPS): {t2 - t1:.3f} s  max|err|={float((r - x).abs().max()):.2e}", flush=True)
     o.compress(0.01); torch.cuda.synchronize(); t3 = time.perf_counter()
@@ -19,14 +22,14 @@ for rep in range(2):
     r = o.to_tensor(as_torch=True); torch.cuda.synchronize(); t4 = time.perf_counter()
     print(f"  to_tensor: {t4 - t3:.3f} s  rel err={float((r - x).norm() / x.norm()):.3e}", flush=True)
 
-if len(sys.argv) > 2 and sys.argv[2] == "oracle":
+if "oracle" in sys.argv[2:]:
     from oracle.ndmps_oracle import OracleNDMPS
     from oracle.metrics import compute_ssim_by_dim
     xh = x.cpu().numpy()
     t0 = time.perf_counter()
     ref = OracleNDMPS.from_tensor(xh, materialise_map=False)
     t1 = time.perf_counter()
-    print(f"oracle exact from_tensor: {t1 - t0:.1f} s bonds={ref.bond_sizes()}", flush=True)
+    print(f"oracle exact from_tensor: {t1 - t0:.1f} s bonds={ref.bond_sizes()}  exact bonds equal: {exact_bonds == ref.bond_sizes()}", flush=True)
     ref.compress(0.01)
     t2 = time.perf_counter()
     print(f"oracle compress(0.01): {t2 - t1:.1f} s bonds={ref.bond_sizes()}", flush=True)
