@@ -10,7 +10,7 @@ exactly those gzip members, in site order, so its payload size IS ``get_bytesize
 
 Header: shape, mode, norm flag, norm_value, dim, qubit_size (site dims), bonds, storage dtype
 ("uint8" / "uint16" = the reference's ``scale_to_dtype`` min-max quantisation, filetools.py:20-39,
-truncating cast; "float32" = lossless cores), per-core (min, max) used by ``scale_back``, per-member
+truncating cast; "float32" / "float64" = lossless cores), per-core (min, max) used by ``scale_back``, per-member
 byte counts.  The factor lists are a pure function of ``shape`` (utils/core.py:79-126) and are rebuilt on
 load.  Quantisation and de-quantisation run on the device (csrc/reduce.hip); gzip runs on the host, as
 in the reference.
@@ -28,7 +28,7 @@ from ..utils import filetools as _ft
 
 MAGIC = b"NDMPS\x01\x00\x00"
 VERSION = 1
-_DTYPES = {"uint8": np.uint8, "uint16": np.uint16, "float32": np.float32}
+_DTYPES = {"uint8": np.uint8, "uint16": np.uint16, "float32": np.float32, "float64": np.float64}
 
 
 def _gzip_member(raw: bytes) -> bytes:
@@ -40,17 +40,19 @@ def _gzip_member(raw: bytes) -> bytes:
 
 def dumps(obj, dtype=np.uint16) -> bytes:
     """Serialise ``obj`` (an NDMPS made by ``from_tensor``) with cores stored as ``dtype``
-    (np.uint8 / np.uint16: the reference's quantisation; np.float32: exact cores)."""
+    (np.uint8 / np.uint16: the reference's quantisation; np.float32 / np.float64: exact cores of fp32 / fp64
+    storage)."""
     if obj._shape is None:
         raise ValueError("this NDMPS was not created by from_tensor; the tensor shape is unknown")
     name = np.dtype(dtype).name
     if name not in _DTYPES:
-        raise ValueError(f"Unsupported dtype {dtype!r}: cores are stored as uint8, uint16 or float32")
+        raise ValueError(f"Unsupported dtype {dtype!r}: cores are stored as uint8, uint16, float32 or float64")
     cores = obj.mps.cores
     members, bounds = [], []
-    if name == "float32":
+    if name in ("float32", "float64"):
         for c in cores:
-            members.append(_gzip_member(c.float().cpu().numpy().tobytes()))
+            host = c.double() if name == "float64" else c.float()
+            members.append(_gzip_member(host.cpu().numpy().tobytes()))
             bounds.append([0.0, 0.0])
     else:
         # the (min, max) scale_to_dtype derives from the data is what scale_back must be given
@@ -164,7 +166,7 @@ def loads(data: bytes, device=None):
             raw = _gunzip_exactly(data[off:off + nbytes], want, i)
             off += nbytes
             arr = np.frombuffer(raw, dtype=_DTYPES[name]).reshape(cshape)
-            if name == "float32":
+            if name in ("float32", "float64"):
                 cores.append(torch.from_numpy(arr.copy()).to(device))
             else:
                 # torch has no uint16: same bytes as int16 storage (what scale_back reads)

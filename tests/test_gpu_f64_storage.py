@@ -263,3 +263,18 @@ def test_overlap_f64_and_mixed_pair():
     c = NDMPS.from_tensor(x, max_bond=20)  # fp32 cores against fp64 cores: contracted in fp64
     dc = np.asarray(omps.mps_to_dense([t.cpu().numpy().astype(np.float64) for t in c.mps.cores])).reshape(-1)
     assert math.isclose(a.mps @ c.mps, float(da @ dc), rel_tol=1e-12)
+
+
+def test_container_round_trip_keeps_fp64_cores(tmp_path):
+    from imgcompressionmps_amd.core import codec
+
+    x = synthetic_mri((32, 32, 32), seed=6).astype(np.float64)
+    obj = NDMPS.from_tensor(x, max_bond=16, dtype=F64)
+    path = tmp_path / "vol.ndmps"
+    codec.save(obj, path, dtype=np.float64)
+    back = codec.load(path)
+    assert all(c.dtype == F64 for c in back.mps.cores)
+    assert np.array_equal(back.to_tensor(), obj.to_tensor())
+    q = codec.loads(codec.dumps(obj, dtype=np.uint16))  # the reference's quantisation, from fp64 cores
+    assert np.abs(q.to_tensor() - obj.to_tensor()).max() <= 1e-2 * np.abs(x).max()
+

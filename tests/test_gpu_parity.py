@@ -697,7 +697,8 @@ def _check_topk(g, w, v, k, tol_scale=1.0, k_max=None):
         assert v[np.argmax(np.abs(v[:, j])), j] > 0
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 33, 64, 100, 128, 129, 130, 200, 257, 512, 777])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 33, 64, 100, 128, 129, 130, 200, 257, 512, 513, 777, 1024, 1100, 2048,
+                               2100])
 def test_topk_solver_against_lapack(n):
     lib = _lib.load()
     rng = np.random.default_rng(n)
@@ -720,6 +721,20 @@ def test_topk_solver_batch_of_mixed_sizes_and_ranks():
         mats.append(a.T @ a)
     for g, k, (w, v) in zip(mats, ks, _topk(lib, mats, ks, k_max=128)):
         _check_topk(g, w, v, k, k_max=128)
+
+
+def test_topk_solver_orders_above_512_in_mixed_batches():
+    """Orders above 512 (BASELINE config 5: 2048; chi = 128 on a 256^3 volume: 1024) take the column launches;
+    batches mix big and small members."""
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for sizes, ks in (([1024, 600, 100, 1000], [128, 64, 10, 128]), ([2048, 1300], [128, 100])):
+        mats = []
+        for n in sizes:
+            a = rng.standard_normal((n + 64, n)) * np.logspace(0, -5, n)[None, :]
+            mats.append(a.T @ a)
+        for g, k, (w, v) in zip(mats, ks, _topk(lib, mats, ks, k_max=128)):
+            _check_topk(g, w, v, k, k_max=128)
 
 
 def test_topk_solver_volume_gram_matrices_with_noise_floor_clusters():
