@@ -543,7 +543,8 @@ gram_partial_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda
 template <int TS>
 __global__ void __launch_bounds__(256)
 tile_reduce_kernel(const double* __restrict__ partial, int n_slabs, int per_group, int n_tiles_1d,
-                   int n_tiles, double* __restrict__ out, double* __restrict__ G, int64_t n, int final) {
+                   int n_tiles, double* __restrict__ out, double* __restrict__ G, int64_t n, int final,
+                   const int32_t* __restrict__ perm = nullptr) {  // perm: element (r, c) goes to (perm[r], perm[c])
   const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= TS * TS) return;
   const int s0 = blockIdx.z * per_group, s1 = min(n_slabs, s0 + per_group);
@@ -569,8 +570,9 @@ tile_reduce_kernel(const double* __restrict__ partial, int n_slabs, int per_grou
   const int tj = ti + tile;
   const int64_t r = (int64_t)ti * TS + e / TS, c = (int64_t)tj * TS + e % TS;
   if (r < n && c < n && (ti != tj || c >= r)) {  // diagonal tiles: upper part mirrored -> exactly symmetric
-    G[r * n + c] = s;
-    G[c * n + r] = s;
+    const int64_t pr = perm ? perm[r] : r, pc = perm ? perm[c] : c;
+    G[pr * n + pc] = s;
+    G[pc * n + pr] = s;
   }
 }
 
@@ -578,11 +580,11 @@ constexpr int kReduceGroup = 16;
 
 template <int TS>
 int launch_tile_reduce(double* partial, int n_slabs, int n_tiles_1d, int n_tiles, double* G, int64_t n,
-                       hipStream_t s) {
+                       hipStream_t s, const int32_t* perm = nullptr) {
   const unsigned ey = (TS * TS + 255) / 256;
   if (n_slabs <= 2 * kReduceGroup) {
     hipLaunchKernelGGL(tile_reduce_kernel<TS>, dim3(n_tiles, ey, 1), dim3(256), 0, s, partial, n_slabs, n_slabs,
-                       n_tiles_1d, n_tiles, (double*)nullptr, G, n, 1);
+                       n_tiles_1d, n_tiles, (double*)nullptr, G, n, 1, perm);
   } else {
     // level 1 writes its group sums behind the slabs (the workspace has room for them)
     const int groups = (n_slabs + kReduceGroup - 1) / kReduceGroup;
@@ -590,7 +592,7 @@ int launch_tile_reduce(double* partial, int n_slabs, int n_tiles_1d, int n_tiles
     hipLaunchKernelGGL(tile_reduce_kernel<TS>, dim3(n_tiles, ey, groups), dim3(256), 0, s, partial, n_slabs,
                        kReduceGroup, n_tiles_1d, n_tiles, lvl, G, n, 0);
     hipLaunchKernelGGL(tile_reduce_kernel<TS>, dim3(n_tiles, ey, 1), dim3(256), 0, s, lvl, groups, groups,
-                       n_tiles_1d, n_tiles, (double*)nullptr, G, n, 1);
+                       n_tiles_1d, n_tiles, (double*)nullptr, G, n, 1, perm);
   }
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
@@ -961,7 +963,8 @@ gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __re
 // G of matrix blockIdx.z from its partial tiles: tile t = blockIdx.x (off-diagonal ones first), element
 // e = blockIdx.y 256 + threadIdx.x; slabs summed in order, four in flight.
 __global__ void __launch_bounds__(256)
-gram128_reduce_kernel(const double* __restrict__ partial, Gram128Geom g, double* __restrict__ G, int64_t stride_G, int64_t n) {
+gram128_reduce_kernel(const double* __restrict__ partial, Gram128Geom g, double* __restrict__ G, int64_t stride_G, int64_t n,
+                      const int32_t* __restrict__ perm) {  // perm (or NULL): element (r, c) goes to (perm[r], perm[c])
   const int e = blockIdx.y * 256 + threadIdx.x;
   const int t = blockIdx.x;
   int ti, tj, base, count;
@@ -992,8 +995,9 @@ gram128_reduce_kernel(const double* __restrict__ partial, Gram128Geom g, double*
   }
   for (; sl < count; ++sl) s += src[(int64_t)sl * 16384];
   double* Gb = G + (int64_t)blockIdx.z * stride_G;
-  Gb[r * n + c] = s;
-  Gb[c * n + r] = s;
+  const int64_t pr = perm ? perm[r] : r, pc = perm ? perm[c] : c;
+  Gb[pr * n + pc] = s;
+  Gb[pc * n + pr] = s;
 }
 
 // ----------------------------------------------------------------------------------
@@ -1308,7 +1312,8 @@ int gram128_opt_in() {
 // G[b] = A[b]^T A[b] for `batch` matrices of one shape (h_A: host array of device pointers)
 template <typename TIN>
 int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int64_t lda, double* d_G, int64_t stride_G,
-                    void* d_ws, int64_t ws_bytes, hipStream_t s, const int64_t* d_row_off, const int64_t* d_col_off) {
+                    void* d_ws, int64_t ws_bytes, hipStream_t s, const int64_t* d_row_off, const int64_t* d_col_off,
+                    const int32_t* d_perm = nullptr) {
   NDMPS_REQUIRE(batch >= 1 && h_A && d_G && gram_use_128(m, n) && lda >= n && stride_G >= n * n,
                 "bad batched Gram argument (batch=%d m=%lld n=%lld)", batch, (long long)m, (long long)n);
   const int64_t need = gram128_workspace(m, n, batch);
@@ -1341,7 +1346,8 @@ int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int6
   // algorithmic work of the span: the upper triangle incl. the diagonal, 2 flops per product
   ndmps::span_end(span, s, ndmps::kSpanGram, (batch + kGram128MaxBatch - 1) / kGram128MaxBatch, (int64_t)batch * m * n * (n + 1));
   if (turn) NDMPS_TRY(ndmps::turn_end(s, ndmps::kTurnGram));
-  hipLaunchKernelGGL(gram128_reduce_kernel, dim3(g.n_off + g.n_diag, 64, batch), dim3(256), 0, s, partial, g, d_G, stride_G, n);
+  hipLaunchKernelGGL(gram128_reduce_kernel, dim3(g.n_off + g.n_diag, 64, batch), dim3(256), 0, s, partial, g, d_G, stride_G, n,
+                     d_perm);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }
@@ -1363,7 +1369,8 @@ extern "C" int64_t ndmps_gram_workspace_bytes(int64_t m, int64_t n) {
 namespace {
 template <typename TIN>
 int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, void* d_ws, int64_t ws_bytes,
-             ndmps_stream_t stream, const int64_t* d_row_off = nullptr, const int64_t* d_col_off = nullptr) {
+             ndmps_stream_t stream, const int64_t* d_row_off = nullptr, const int64_t* d_col_off = nullptr,
+             const int32_t* d_perm = nullptr) {
   NDMPS_REQUIRE(d_A && d_G, "NULL Gram operand");
   NDMPS_REQUIRE(m > 0 && n > 0 && lda >= n, "bad Gram extents m=%lld n=%lld lda=%lld", (long long)m,
                 (long long)n, (long long)lda);
@@ -1376,6 +1383,7 @@ int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, voi
   double* partial = (double*)d_ws;
   // four elements per load: 16 bytes of fp32, 8 bytes of bf16
   const int vec_ok = (lda % 4 == 0 && n % 4 == 0 && ((uintptr_t)d_A % (4 * sizeof(TIN))) == 0) ? 1 : 0;
+  NDMPS_REQUIRE(!d_perm || d_row_off, "a column permutation comes with the offset tables");
   if (d_row_off) {
     NDMPS_REQUIRE(d_col_off && gram_use_wide(m, n) && n % 4 == 0 && ((uintptr_t)d_A % (4 * sizeof(TIN))) == 0,
                   "gathered Gram needs the wide path (n >= 64, m >= 256), n %% 4 == 0 and an aligned base");
@@ -1388,14 +1396,15 @@ int gram_any(const TIN* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, voi
     NDMPS_LAUNCH_CHECK();
     return NDMPS_OK;
   }
-  if (gram_use_128(m, n)) return gram128_batched<TIN>(1, &d_A, m, n, lda, d_G, n * n, d_ws, ws_bytes, s, d_row_off, d_col_off);
+  if (gram_use_128(m, n))
+    return gram128_batched<TIN>(1, &d_A, m, n, lda, d_G, n * n, d_ws, ws_bytes, s, d_row_off, d_col_off, d_perm);
   if (gram_use_wide(m, n)) {
     GramGeom gw = gram_wide_geometry(m, n);
     NDMPS_REQUIRE(gw.n_slabs < 65536, "Gram slab count %d exceeds grid.y", gw.n_slabs);
     hipLaunchKernelGGL((gram_wide_kernel<64, TIN>), dim3(gw.n_tiles, gw.n_slabs), dim3(256), 0, s, d_A, m, n, lda,
                        partial, gw.tiles_1d, gw.rows_per_slab, vec_ok, d_row_off, d_col_off);
     NDMPS_LAUNCH_CHECK();
-    return launch_tile_reduce<64>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s);
+    return launch_tile_reduce<64>(partial, gw.n_slabs, gw.tiles_1d, gw.n_tiles, d_G, n, s, d_perm);
   }
   GramGeom g = gram_geometry(m, n);
   NDMPS_REQUIRE(g.n_slabs < 65536, "Gram slab count %d exceeds grid.y", g.n_slabs);
@@ -1421,12 +1430,15 @@ extern "C" int ndmps_gram_f32(const float* d_A, int64_t m, int64_t n, int64_t ld
 }
 
 // G = A^T A where element (r, c) of A is d_base[d_row_off[r] + d_col_off[c]] (the C-order volume read through the
-// index permutation; d_col_off in aligned runs of four consecutive offsets); wide path only (n >= 64, m >= 256)
+// index permutation; d_col_off in aligned runs of four consecutive offsets); wide path only (n >= 64, m >= 256).
+// d_col_perm (may be NULL): the columns were visited in another order than the caller numbers them (memory order
+// of the volume); entry (a, b) of the product is stored at G[d_col_perm[a]][d_col_perm[b]] by the slab reduction
+// itself (a separate pass over a group's 512 x 512 matrices took 0.47 ms per launch of 32).
 extern "C" int ndmps_gram_indexed_f32(const float* d_base, int64_t m, int64_t n, const int64_t* d_row_off,
-                                      const int64_t* d_col_off, double* d_G, void* d_ws, int64_t ws_bytes,
-                                      ndmps_stream_t stream) {
+                                      const int64_t* d_col_off, const int32_t* d_col_perm, double* d_G, void* d_ws,
+                                      int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_row_off && d_col_off, "NULL offset table");
-  return gram_any<float>(d_base, m, n, n, d_G, d_ws, ws_bytes, stream, d_row_off, d_col_off);
+  return gram_any<float>(d_base, m, n, n, d_G, d_ws, ws_bytes, stream, d_row_off, d_col_off, d_col_perm);
 }
 
 // Batched Gram of `batch` matrices of one shape (n >= 128, m >= 256): h_A[b] (host array of device pointers) ->
@@ -1447,11 +1459,12 @@ extern "C" int ndmps_gram_batched_bf16(int batch, const void* const* h_A, int64_
                                  (hipStream_t)stream, nullptr, nullptr);
 }
 extern "C" int ndmps_gram_batched_indexed_f32(int batch, const float* const* h_base, int64_t m, int64_t n,
-                                              const int64_t* d_row_off, const int64_t* d_col_off, double* d_G,
-                                              int64_t stride_G, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+                                              const int64_t* d_row_off, const int64_t* d_col_off,
+                                              const int32_t* d_col_perm, double* d_G, int64_t stride_G, void* d_ws,
+                                              int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_row_off && d_col_off, "NULL offset table");
   return gram128_batched<float>(batch, h_base, m, n, n, d_G, stride_G, d_ws, ws_bytes, (hipStream_t)stream, d_row_off,
-                                d_col_off);
+                                d_col_off, d_col_perm);
 }
 
 // fp64 storage (the reference's own element type, core/ndmps.py:56): the matrix is read as fp64 straight from global

@@ -257,16 +257,8 @@ __global__ void merge_basis_init_kernel(double* __restrict__ W, int64_t stride_w
 }
 
 // Fused reshape stage: the raw Gram pass reads the volume with its columns in MEMORY order (perm[c'] = site-order
-// column of the c'-th smallest offset): G'[a][b] = G[perm[a]][perm[b]].  Back to site order:
-__global__ void __launch_bounds__(256)
-unpermute_gram_kernel(const double* __restrict__ Gp, int64_t n, const int32_t* __restrict__ perm, double* __restrict__ G,
-                      int64_t stride) {  // matrix blockIdx.y at Gp / G + blockIdx.y * stride
-  const int64_t total = n * n;
-  Gp += (int64_t)blockIdx.y * stride;
-  G += (int64_t)blockIdx.y * stride;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
-    G[(int64_t)perm[e / n] * n + perm[e % n]] = Gp[e];
-}
+// column of the c'-th smallest offset) and its slab reduction stores G'[a][b] at G[perm[a]][perm[b]]
+// (ndmps_gram_indexed_f32) ...
 // ... and the projection multiplies by the basis with its rows in memory order: out[c'] = W[perm[c']]
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ W, int64_t rows, int64_t cols, const int32_t* __restrict__ perm,
@@ -502,7 +494,7 @@ inline int gram_batched_src(int, const double* const*, int64_t, int64_t, const S
 }
 inline int gram_batched_src(int batch, const float* const* vol, int64_t m, int64_t n, const SweepSource& src, double* G,
                             int64_t stride, void* ws, int64_t wsb, hipStream_t s) {
-  return ndmps_gram_batched_indexed_f32(batch, vol, m, n, src.row_off, src.col_off, G, stride, ws, wsb, s);
+  return ndmps_gram_batched_indexed_f32(batch, vol, m, n, src.row_off, src.col_off, src.col_perm, G, stride, ws, wsb, s);
 }
 inline int gram_batched_src(int, const __bf16* const*, int64_t, int64_t, const SweepSource&, double*, int64_t, void*,
                             int64_t, hipStream_t) {
@@ -554,7 +546,7 @@ inline bool gemm_batched_T(int, int, int64_t, int64_t, int64_t, __bf16* const*, 
 // fp32 only: Gram and projection of the merged run through the permutation tables
 inline int gram_src(const float* vol, int64_t m, int64_t n, const SweepSource& src, double* G, void* ws, int64_t wsb,
                     hipStream_t s) {
-  return ndmps_gram_indexed_f32(vol, m, n, src.row_off, src.col_off, G, ws, wsb, s);
+  return ndmps_gram_indexed_f32(vol, m, n, src.row_off, src.col_off, src.col_perm, G, ws, wsb, s);
 }
 inline int gram_src(const __bf16*, int64_t, int64_t, const SweepSource&, double*, void*, int64_t, hipStream_t) {
   ndmps::set_error("the fused reshape stage is fp32 only");
@@ -728,22 +720,15 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     const int64_t raw_batched = gram_batched_need<T>(batch, m0, n0);
     if (batch > 1 && raw_batched > 0 && raw_batched <= lay.gram_ws) {
       // the whole group in one launch (long slabs: a fraction of the partial tiles, no launch gaps)
-      if (src) {
-        NDMPS_TRY(gram_batched_src(batch, cur.data(), m0, n0, *src, Tm, stride_top, gram_ws, lay.gram_ws, s));
-        hipLaunchKernelGGL(unpermute_gram_kernel, dim3(grid1d(n0 * n0), batch), dim3(256), 0, s, Tm, n0, src->col_perm,
-                           Graw, stride_top);
-        NDMPS_LAUNCH_CHECK();
+      if (src) {  // columns visited in memory order; the slab reduction stores the result in site order
+        NDMPS_TRY(gram_batched_src(batch, cur.data(), m0, n0, *src, Graw, stride_top, gram_ws, lay.gram_ws, s));
       } else {
         NDMPS_TRY(gram_batched_T(batch, cur.data(), m0, n0, Graw, stride_top, gram_ws, lay.gram_ws, s));
       }
     } else {
       for (int b = 0; b < batch; ++b) {
         if (src) {
-          double* Gp = Tm + (int64_t)b * stride_top;  // columns in memory order; T is free until stage 1
-          NDMPS_TRY(gram_src(cur[b], m0, n0, *src, Gp, gram_ws, lay.gram_ws, s));
-          hipLaunchKernelGGL(unpermute_gram_kernel, dim3(grid1d(n0 * n0), 1), dim3(256), 0, s, Gp, n0, src->col_perm,
-                             Graw + (int64_t)b * stride_top, stride_top);
-          NDMPS_LAUNCH_CHECK();
+          NDMPS_TRY(gram_src(cur[b], m0, n0, *src, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
         } else {
           NDMPS_TRY(gram_T(cur[b], m0, n0, n0, Graw + (int64_t)b * stride_top, gram_ws, lay.gram_ws, s));
         }

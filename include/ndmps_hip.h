@@ -176,8 +176,9 @@ int ndmps_gram_batched_f32(int batch, const float* const* h_A, int64_t m, int64_
 int ndmps_gram_batched_bf16(int batch, const void* const* h_A, int64_t m, int64_t n, int64_t lda, double* d_G,
                             int64_t stride_G, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
 int ndmps_gram_batched_indexed_f32(int batch, const float* const* h_base, int64_t m, int64_t n,
-                                   const int64_t* d_row_off, const int64_t* d_col_off, double* d_G,
-                                   int64_t stride_G, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+                                   const int64_t* d_row_off, const int64_t* d_col_off,
+                                   const int32_t* d_col_perm, double* d_G, int64_t stride_G, void* d_ws,
+                                   int64_t ws_bytes, ndmps_stream_t stream);
 
 /* G = A^T A for a bf16 matrix A (products exact, fp64 accumulation); workspace as ndmps_gram_f32 */
 int ndmps_gram_bf16(const void* d_A, int64_t m, int64_t n, int64_t lda, double* d_G, void* d_ws,
@@ -295,10 +296,12 @@ int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h_volume, in
                                      const int64_t* d_row_off, const int64_t* d_col_off,
                                      const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
                                      int64_t ws_bytes, ndmps_stream_t stream);
-/* G = A^T A where element (r, c) of A is d_base[d_row_off[r] + d_col_off[c]] (wide path: n >= 64, m >= 256) */
+/* G = A^T A where element (r, c) of A is d_base[d_row_off[r] + d_col_off[c]] (wide path: n >= 64, m >= 256);
+ * d_col_perm (may be NULL): entry (a, b) of the product is stored at G[d_col_perm[a]][d_col_perm[b]] -- the columns
+ * were visited in the memory order of the volume, the result comes out in site order */
 int ndmps_gram_indexed_f32(const float* d_base, int64_t m, int64_t n, const int64_t* d_row_off,
-                           const int64_t* d_col_off, double* d_G, void* d_ws, int64_t ws_bytes,
-                           ndmps_stream_t stream);
+                           const int64_t* d_col_off, const int32_t* d_col_perm, double* d_G, void* d_ws,
+                           int64_t ws_bytes, ndmps_stream_t stream);
 
 /* The same sweep on bf16 storage: site-order tensors, carried matrices and cores are bf16 in HBM, Gram
  * matrices / eigen-decompositions / bases fp64, products fp32-accumulated on the bf16 MFMA.  Layout and

@@ -1411,3 +1411,38 @@ def test_degenerate_inputs_match_the_oracle(name, kw):
     assert abs(g.norm_value - o.norm_value) <= 2e-6 * o.norm_value
     if not kw.get("max_bond"):
         assert np.abs(rg - x).max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("m,n,batch", [(4096, 512, 1), (2048, 256, 3), (1024, 96, 1), (600, 64, 1)])
+def test_gathered_gram_stores_its_result_through_the_column_permutation(m, n, batch):
+    """The raw Gram of the fused sweep visits the columns in memory order (d_col_off ascending) and its slab
+    reduction stores entry (a, b) at G[perm[a]][perm[b]]: the result equals the Gram of the gathered matrix with
+    its columns in the caller's order."""
+    lib = _lib.load()
+    rng = np.random.default_rng(m + n)
+    quads = rng.permutation(n // 4)
+    perm = (4 * quads[:, None] + np.arange(4)[None, :]).reshape(-1).astype(np.int32)   # site-order column of position a
+    col_off = np.arange(n, dtype=np.int64)                                             # position a reads offset a
+    row_off = rng.permutation(m).astype(np.int64) * n
+    bases = [rng.standard_normal(m * n).astype(np.float32) for _ in range(batch)]
+    d_b = [dev(b) for b in bases]
+    t_r, t_c, t_p = dev(row_off), dev(col_off), dev(perm)
+    out = torch.zeros((batch, n, n), dtype=torch.float64, device=DEV)
+    if batch == 1:
+        nbytes = lib.ndmps_gram_workspace_bytes(m, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.ndmps_gram_indexed_f32(d_b[0].data_ptr(), m, n, t_r.data_ptr(), t_c.data_ptr(), t_p.data_ptr(),
+                                              out.data_ptr(), ws.data_ptr(), nbytes, sp()))
+    else:
+        nbytes = lib.ndmps_gram_batched_workspace_bytes(batch, m, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        ptrs = (C.c_void_p * batch)(*[t.data_ptr() for t in d_b])
+        _lib.check(lib.ndmps_gram_batched_indexed_f32(batch, ptrs, m, n, t_r.data_ptr(), t_c.data_ptr(), t_p.data_ptr(),
+                                                      out.data_ptr(), n * n, ws.data_ptr(), nbytes, sp()))
+    got = out.cpu().numpy()
+    for z in range(batch):
+        a = bases[z][row_off[:, None] + col_off[None, :]].astype(np.float64)   # columns in visiting order
+        ref = np.empty((n, n))
+        ref[np.ix_(perm, perm)] = a.T @ a
+        assert np.abs(got[z] - ref).max() <= 1e-13 * np.abs(ref).max() * math.sqrt(m)
+        assert np.array_equal(got[z], got[z].T)

@@ -31,7 +31,7 @@ def plain():
 
 
 def gathered():
-    _lib.check(lib.ndmps_gram_batched_indexed_f32(batch, ptrs, m, n, row_off.data_ptr(), col_off.data_ptr(), out.data_ptr(),
+    _lib.check(lib.ndmps_gram_batched_indexed_f32(batch, ptrs, m, n, row_off.data_ptr(), col_off.data_ptr(), None, out.data_ptr(),
                                                   n * n, ws.data_ptr(), nb, sp))
 
 
