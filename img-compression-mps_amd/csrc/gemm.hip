@@ -801,7 +801,13 @@ __device__ __forceinline__ void gram128_chunk(const float* pa, const float* pb, 
   }
 }
 
-template <typename TIN>
+// MODE 0: any shape (guarded, per-lane branches in the fetch).  MODE 1 (plain rows) / 2 (rows and columns through
+// the offset tables): every chunk is interior -- whole 128-column panels, slabs of whole 32-row chunks, 16-byte
+// loads -- and the fetch is eight straight-line loads.  In MODE 0 every load sits in an exec-masked block and carries
+// its own s_waitcnt vmcnt(0) (the registers it overwrites may still be the target of a load of the previous trip,
+// and a wait inside a skipped block clears nothing at the join): the eight loads of a chunk go out one after the
+// other, each waiting for the one before, in front of the chunk's MFMAs.
+template <typename TIN, int MODE>
 __global__ void __launch_bounds__(256, 2)
 gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __restrict__ partial, Gram128Geom g,
                int vec_ok, const int64_t* __restrict__ row_off, const int64_t* __restrict__ col_off) {
@@ -841,7 +847,7 @@ gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __re
   // front of the data loads, and the wave sat through it before it could start the chunk's MFMAs (+18 %)
   int64_t coli = 0, colj = 0, ro[4] = {0, 0, 0, 0};
   auto row_offsets = [&](int64_t r0) {
-    if (row_off) {
+    if (MODE == 2 || (MODE == 0 && row_off)) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int64_t row = r0 + (tid + 256 * v) / 32;
@@ -849,12 +855,29 @@ gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __re
       }
     }
   };
-  if (row_off) {
+  if (MODE == 2 || (MODE == 0 && row_off)) {
     const int c4 = (tid % 32) * 4;
     if (i0 + c4 + 3 < n) coli = col_off[i0 + c4];
     if (j0 + c4 + 3 < n) colj = col_off[j0 + c4];
   }
   auto fetch = [&](int64_t r0) {
+    if constexpr (MODE != 0) {
+      // interior chunk: straight-line loads, the raw elements converted on their way to LDS (stash)
+      const int c4 = (tid % 32) * 4;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const TIN* src = MODE == 2 ? A + ro[v] + coli : A + (r0 + (tid + 256 * v) / 32) * lda + i0 + c4;
+        pi[v] = load4_as_f32(src);
+      }
+      if (!diag) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const TIN* src = MODE == 2 ? A + ro[v] + colj : A + (r0 + (tid + 256 * v) / 32) * lda + j0 + c4;
+          pj[v] = load4_as_f32(src);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int e = tid + 256 * v;
@@ -1301,10 +1324,16 @@ int gram128_opt_in() {
   NDMPS_CHECK_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(mu);
   if (dev < 0 || dev >= 64 || done[dev]) return NDMPS_OK;
-  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram128_kernel<float>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGram128Lds));
-  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram128_kernel<__bf16>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGram128Lds));
+#define NDMPS_GRAM128_OPT_IN(T, MODE)                                                                          \
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram128_kernel<T, MODE>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGram128Lds))
+  NDMPS_GRAM128_OPT_IN(float, 0);
+  NDMPS_GRAM128_OPT_IN(float, 1);
+  NDMPS_GRAM128_OPT_IN(float, 2);
+  NDMPS_GRAM128_OPT_IN(__bf16, 0);
+  NDMPS_GRAM128_OPT_IN(__bf16, 1);
+  NDMPS_GRAM128_OPT_IN(__bf16, 2);
+#undef NDMPS_GRAM128_OPT_IN
   done[dev] = true;
   return NDMPS_OK;
 }
@@ -1340,7 +1369,11 @@ int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int6
     const int count = std::min(kGram128MaxBatch, batch - base);
     Gram128Ptrs ptrs;
     for (int t = 0; t < count; ++t) ptrs.a[t] = h_A[base + t];
-    hipLaunchKernelGGL(gram128_kernel<TIN>, dim3(g.slots, count), dim3(256), kGram128Lds, s, ptrs, m, n, lda,
+    // every chunk interior (whole panels, whole 32-row chunks, 16-byte loads): the straight-line fetch
+    const bool interior = vec_ok && n % 128 == 0 && m % GW_KB == 0 && g.rows_off % GW_KB == 0 && g.rows_diag % GW_KB == 0 &&
+                          !getenv("NDMPS_GRAM_GENERAL");
+    auto kernel = !interior ? gram128_kernel<TIN, 0> : (d_row_off ? gram128_kernel<TIN, 2> : gram128_kernel<TIN, 1>);
+    hipLaunchKernelGGL(kernel, dim3(g.slots, count), dim3(256), kGram128Lds, s, ptrs, m, n, lda,
                        partial + (int64_t)base * g.slots * 16384, g, vec_ok, d_row_off, d_col_off);
   }
   // algorithmic work of the span: the upper triangle incl. the diagonal, 2 flops per product
