@@ -86,7 +86,9 @@ struct GemmIndex {
   const int64_t* a_col;
   const int64_t* c_row;
   const int64_t* c_col;
+  int guarded;  // A/B (NDMPS_GEMM_GUARDED): every tile through the guarded fetch
 };
+inline int gemm_guarded_env() { return getenv("NDMPS_GEMM_GUARDED") ? 1 : 0; }
 
 // operands of a batch of products of one shape: product blockIdx.z uses a[z], b[z], c[z] (kernel arguments)
 constexpr int kGemmMaxBatch = 64;
@@ -152,9 +154,30 @@ gemm_body(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
     }
   }
 
+  // Tiles that lie inside the matrices (and k-tiles inside K) are fetched by straight-line code: a load inside a
+  // per-lane guard sits in an exec-masked block behind its own s_waitcnt vmcnt(0) (see gram128_kernel), so the
+  // guarded quads of a k-tile went out one memory round trip after the other.
+  const bool inner_a = VA && m0 + BM <= M && !ix.guarded, inner_b = VB && n0 + BN <= N && !ix.guarded;
   // op(A)[m][k]: stored (M, K) unless TA (then (K, M)).  contiguous axis: k unless TA (then m)
   auto fetch_a = [&](int64_t k0) {
-    if (VA) {
+    if (VA && inner_a && k0 + BK <= K) {
+#pragma unroll
+      for (int i = 0; i < A_PER / 4; ++i) {
+        const int e = tid + 256 * i;  // quad index
+        const T* src;
+        if (TA) {
+          src = A + (k0 + e / (BM / 4)) * lda + m0 + (e % (BM / 4)) * 4;
+        } else {
+          const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
+          if (IDX && idx_fast) src = A + arow_q[i] + acol_s[k0 + k];
+          else if (IDX && ix.a_row) src = A + ix.a_row[m0 + m] + ix.a_col[k0 + k];
+          else src = A + (m0 + m) * lda + k0 + k;
+        }
+        const Quad<T> q = *reinterpret_cast<const Quad<T>*>(src);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[4 * i + j] = q.v[j];
+      }
+    } else if (VA) {
 #pragma unroll
       for (int i = 0; i < A_PER / 4; ++i) {
         const int e = tid + 256 * i;  // quad index
@@ -193,7 +216,17 @@ gemm_body(int64_t M, int64_t N, int64_t K, const T* __restrict__ A, int64_t lda,
     }
   };
   auto fetch_b = [&](int64_t k0) {
-    if (VB) {
+    if (VB && inner_b && k0 + BK <= K) {
+#pragma unroll
+      for (int i = 0; i < B_PER / 4; ++i) {
+        const int e = tid + 256 * i;
+        const T* src = TB ? B + (n0 + e / (BK / 4)) * ldb + k0 + (e % (BK / 4)) * 4
+                          : B + (k0 + e / (BN / 4)) * ldb + n0 + (e % (BN / 4)) * 4;
+        const Quad<T> q = *reinterpret_cast<const Quad<T>*>(src);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[4 * i + j] = q.v[j];
+      }
+    } else if (VB) {
 #pragma unroll
       for (int i = 0; i < B_PER / 4; ++i) {
         const int e = tid + 256 * i;
@@ -417,6 +450,7 @@ int launch_gemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const T
                 int batch = 1) {
   dim3 grid((unsigned)ndmps::ceil_div(m, BM), (unsigned)ndmps::ceil_div(n, BN), (unsigned)batch);
   dim3 block(256);
+  GemmIndex gi{nullptr, nullptr, nullptr, nullptr, gemm_guarded_env()};
   // vector path: whole quads are either inside or outside every bound, and 4-element aligned
   const uintptr_t al = sizeof(T) * 4;
   bool vec = lda % 4 == 0 && ldb % 4 == 0 && k % 4 == 0 && (!transA || m % 4 == 0) && (transB || n % 4 == 0);
@@ -429,10 +463,10 @@ int launch_gemm(int transA, int transB, int64_t m, int64_t n, int64_t k, const T
   do {                                                                                                              \
     if (bp)                                                                                                         \
       hipLaunchKernelGGL((gemm_batched_kernel<T, BM, BN, WAVES_M, WAVES_N, TA_, TB_, V_>), grid, block, 0, stream,  \
-                         m, n, k, *bp, lda, ldb, ldc);                                                              \
+                         m, n, k, *bp, lda, ldb, ldc, gi);                                                          \
     else                                                                                                            \
       hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TA_, TB_, V_>), grid, block, 0, stream, m, n, k,  \
-                         A, lda, B, ldb, C, ldc);                                                                   \
+                         A, lda, B, ldb, C, ldc, gi);                                                               \
   } while (0)
 #define NDMPS_GEMM_TRANS(V_)                                     \
   do {                                                           \
@@ -1142,7 +1176,7 @@ extern "C" int ndmps_sgemm_indexed(int64_t m, int64_t n, int64_t k, const float*
   NDMPS_REQUIRE(ldb >= n && (d_a_row || lda >= k) && (d_c_row || ldc >= n), "leading dimension too small");
   if (m == 0 || n == 0) return NDMPS_OK;
   hipStream_t s = (hipStream_t)stream;
-  GemmIndex ix{d_a_row, d_a_col, d_c_row, d_c_col};
+  GemmIndex ix{d_a_row, d_a_col, d_c_row, d_c_col, gemm_guarded_env()};
   const uintptr_t al = 16;
   const bool vec = ldb % 4 == 0 && k % 4 == 0 && n % 4 == 0 && (uintptr_t)d_A % al == 0 && (uintptr_t)d_B % al == 0 &&
                    (d_a_row ? a_vec4 != 0 : lda % 4 == 0);
@@ -1245,7 +1279,7 @@ extern "C" int ndmps_sgemm_indexed_batched(int batch, int64_t m, int64_t n, int6
   NDMPS_REQUIRE(ldb >= n && (d_a_row || lda >= k) && (d_c_row || ldc >= n), "leading dimension too small");
   if (m == 0 || n == 0) return NDMPS_OK;
   hipStream_t s = (hipStream_t)stream;
-  GemmIndex ix{d_a_row, d_a_col, d_c_row, d_c_col};
+  GemmIndex ix{d_a_row, d_a_col, d_c_row, d_c_col, gemm_guarded_env()};
   const uintptr_t al = 16;
   bool vec = ldb % 4 == 0 && k % 4 == 0 && n % 4 == 0 && (d_a_row ? a_vec4 != 0 : lda % 4 == 0);
   for (int z = 0; z < batch; ++z) vec = vec && (uintptr_t)bp.a[z] % al == 0 && (uintptr_t)bp.b[z] % al == 0;
