@@ -1,0 +1,163 @@
+"""One tensor too large for one GPU: the bond-capped sweep with the ROWS of every unfolding sharded over ranks
+(BASELINE config 5 "1 and 8 GPUs").
+
+The right-to-left sweep (``MatrixProductState.from_dense``, core/ndmps.py:74 of the reference) needs, per site, the
+Gram matrix of the unfolding ``A_i`` (rows = the sites to the left, ``n_i = d_i chi_{i+1}`` columns).  Rows split
+over ranks cleanly: rank r holds a contiguous block of the rows of the SITE-ORDER tensor (for 2^k cubes and R = d_0
+ranks: one octant of the volume, in its own site order), and
+
+    G_i = sum_r A_i[r]^T A_i[r]                      -- the one real exchange step: an all-reduce of n_i x n_i fp64
+
+after which every rank solves the same eigenproblem (same bits in, same bits out: the solver is deterministic),
+keeps the same core and projects its own rows.  When the rows to the left are no longer more than the columns, the
+carried matrix (at most a few MB) is all-gathered and every rank finishes the remaining sites with the ordinary
+single-GPU sweep: the carried matrix of site i is a tensor over the sites 0..i-1 with ``d_i chi_{i+1}`` as its last
+"site", whose core is core i.  The result is a replicated ``DeviceMPS``; ``local_dense`` reconstructs a rank's own
+rows only.
+
+Every product, Gram matrix and eigen-decomposition is a kernel of libndmps_hip.so (ndmps_gram_f32,
+ndmps_syevd_topk_*, ndmps_sgemm, ndmps_tt_sweep_f32, ndmps_chain_contract_f32); torch.distributed carries the two
+collectives (backend "nccl" = RCCL over xGMI on a node; "gloo" in the tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from .mps import DeviceMPS
+
+_CUTOFF_FLOOR = 1e-6  # csrc/tt.hip kCutoffFloor: fp32 data
+
+
+def _kept(sigma, cutoff, max_bond):
+    c = max(float(cutoff), _CUTOFF_FLOOR)
+    k = int(np.count_nonzero(sigma > c * sigma[0]))
+    return max(1, min(k, int(max_bond), len(sigma)))
+
+
+def from_dense_sharded(local_dense, dims, max_bond, cutoff: float = 1e-10, group=None) -> DeviceMPS:
+    """``local_dense``: this rank's rows of the site-order tensor, a device fp32 tensor of
+    ``prod(dims) / world`` elements (rank r holds rows ``[r, r + 1) * prod(dims) / world`` of the flattened tensor;
+    ``world`` must divide ``dims[0]``).  ``dims``: the site dimensions of the FULL tensor.  Returns the MPS of the full
+    tensor, replicated on every rank.  ``local_dense`` is left untouched."""
+    import torch
+    import torch.distributed as dist
+
+    lib = _lib.load()
+    _lib.require_device()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    dims = [int(d) for d in dims]
+    L = len(dims)
+    if not max_bond or int(max_bond) > int(lib.ndmps_syevd_topk_max_k()):
+        raise ValueError(f"the sharded sweep needs 1 <= max_bond <= {int(lib.ndmps_syevd_topk_max_k())}")
+    chi = int(max_bond)
+    numel = int(np.prod(dims, dtype=np.int64))
+    if dims[0] % world != 0:
+        raise ValueError(f"the number of ranks ({world}) must divide the first site dimension ({dims[0]})")
+    if local_dense.numel() * world != numel or local_dense.dtype != torch.float32 or not local_dense.is_cuda:
+        raise ValueError("local_dense must be this rank's prod(dims) / world fp32 elements on the device")
+    device = local_dense.device
+    stream = _lib.stream_ptr()
+    cores = [None] * L
+    carried = local_dense.reshape(-1)          # (rows_local, n_i) row-major, rows_local = rows_global / world
+    chi_r = 1
+    i = L - 1
+    with torch.cuda.device(device):
+        while i >= 1:
+            n = dims[i] * chi_r
+            rows_global = int(np.prod(dims[:i], dtype=np.int64))
+            rows_local = rows_global // world
+            # sharded while the unfolding is tall on every rank and the eigenproblem fits the direct solver
+            if rows_local < max(n, 256) or n > int(lib.ndmps_syevd_topk_max_n()):
+                break
+            a = carried
+            g = torch.empty((n, n), dtype=torch.float64, device=device)
+            nbytes = int(lib.ndmps_gram_workspace_bytes(rows_local, n))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            _lib.check(lib.ndmps_gram_f32(a.data_ptr(), rows_local, n, n, g.data_ptr(), ws.data_ptr(), nbytes, stream))
+            if world > 1:
+                dist.all_reduce(g, group=group)  # the exchange step: Gram matrices of the row blocks add up
+            k_max = min(chi, n)
+            v = torch.empty((n, n), dtype=torch.float64, device=device)
+            w = torch.empty(n, dtype=torch.float64, device=device)
+            ebytes = int(lib.ndmps_syevd_topk_workspace_bytes(n, 1, k_max))
+            ews = torch.empty(ebytes, dtype=torch.uint8, device=device)
+            sizes = _lib.i64_array([n])
+            _lib.check(lib.ndmps_syevd_topk_values_f64(1, g.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(), n,
+                                                       k_max, ews.data_ptr(), ebytes, stream))
+            sigma = np.sqrt(np.maximum(w.cpu().numpy()[:k_max], 0.0))
+            k = _kept(sigma, cutoff, chi)
+            status = (C.c_int * 1)()
+            _lib.check(lib.ndmps_syevd_topk_vectors_f64(1, sizes, _lib.i64_array([k]), k_max, ews.data_ptr(), ebytes, status,
+                                                        stream))
+            if status[0] != 0:
+                raise _lib.NdmpsHipError(f"site {i}: the eigen-solver reported status {status[0]}")
+            basis = v[:, :k].to(torch.float32).contiguous()            # (n, k): the k leading eigenvectors
+            cores[i] = basis.t().contiguous().view(k, dims[i], chi_r)  # rows of V^T, like the single-GPU sweep
+            nxt = torch.empty(rows_local * k, dtype=torch.float32, device=device)
+            _lib.check(lib.ndmps_sgemm(0, 0, rows_local, k, n, a.data_ptr(), n, basis.data_ptr(), k, nxt.data_ptr(), k, stream))
+            carried, chi_r = nxt, k
+            i -= 1
+        # ---- the rest on every rank: gather the carried matrix (rows of sites 0..i, chi_r columns)
+        if world > 1:
+            parts = [torch.empty_like(carried) for _ in range(world)]
+            dist.all_gather(parts, carried.contiguous(), group=group)
+            full = torch.cat(parts)
+        else:
+            full = carried.clone()  # the ordinary sweep works in place
+        head = dims[:i] + [dims[i] * chi_r]     # the carried matrix as a tensor whose last "site" is (d_i, chi_{i+1})
+        Lh = len(head)
+        cdims = _lib.i64_array(head)
+        max_bonds = (C.c_int64 * (Lh + 1))()
+        core_off = (C.c_int64 * (Lh + 1))()
+        spec_off = (C.c_int64 * (Lh + 1))()
+        wsb = C.c_int64()
+        _lib.check(lib.ndmps_tt_layout(Lh, cdims, chi, max_bonds, core_off, spec_off, C.byref(wsb)))
+        arena = torch.zeros(int(core_off[Lh]) + 64, dtype=torch.float32, device=device)
+        ws = torch.empty(int(wsb.value), dtype=torch.uint8, device=device)
+        bonds = (C.c_int64 * (Lh + 1))()
+        spectra = (C.c_double * max(int(spec_off[Lh]), 1))()
+        _lib.check(lib.ndmps_tt_sweep_f32(full.data_ptr(), Lh, cdims, float(cutoff), chi, arena.data_ptr(), core_off, bonds,
+                                          spectra, spec_off, ws.data_ptr(), int(wsb.value), stream))
+        padded = bool(lib.ndmps_tt_sweep_pads_cores(Lh, cdims, chi))
+        for j in range(Lh):
+            k0, k1 = int(bonds[j]), int(bonds[j + 1])
+            if padded:
+                c0, c1 = int(max_bonds[j]), int(max_bonds[j + 1])
+                blk = arena[int(core_off[j]): int(core_off[j]) + c0 * head[j] * c1].view(c0, head[j], c1)[:k0, :, :k1]
+            else:
+                blk = arena[int(core_off[j]): int(core_off[j]) + k0 * head[j] * k1].view(k0, head[j], k1)
+            blk = blk.contiguous().clone()
+            cores[j] = blk.view(k0, dims[i], chi_r) if j == Lh - 1 else blk
+    return DeviceMPS(cores)
+
+
+def local_dense(mps: DeviceMPS, rank: int, world: int):
+    """This rank's rows of the site-order tensor the MPS stands for (``prod(dims) / world`` elements): the chain
+    contraction with the first core restricted to the rank's block of the first site.  The restricted first core
+    is multiplied into its right neighbours until it has at least as many rows as columns, so that what is handed
+    to the chain kernel is again an MPS whose bonds respect the unfolding ranks."""
+    import torch
+
+    lib = _lib.load()
+    dims, L = mps.dims, len(mps.cores)
+    if dims[0] % world != 0:
+        raise ValueError("world must divide the first site dimension")
+    step = dims[0] // world
+    device = mps.device
+    with torch.cuda.device(device):
+        cur = mps.cores[0][0, rank * step:(rank + 1) * step, :].to(torch.float32).contiguous()  # (rows, chi_1)
+        rows, j = step, 1
+        while j < L - 1 and rows < cur.shape[1]:
+            core = mps.cores[j].to(torch.float32).contiguous()
+            chi_j, d_j, chi_n = (int(x) for x in core.shape)
+            out = torch.empty((rows, d_j * chi_n), dtype=torch.float32, device=device)
+            _lib.check(lib.ndmps_sgemm(0, 0, rows, d_j * chi_n, chi_j, cur.data_ptr(), chi_j, core.data_ptr(), d_j * chi_n,
+                                       out.data_ptr(), d_j * chi_n, _lib.stream_ptr()))
+            rows *= d_j
+            cur = out.view(rows, chi_n)
+            j += 1
+        head = cur.reshape(1, rows, cur.shape[1]).contiguous()
+        return DeviceMPS([head] + [c.to(torch.float32) for c in mps.cores[j:]]).to_dense()

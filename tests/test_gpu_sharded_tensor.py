@@ -1,0 +1,104 @@
+"""One tensor sharded by rows over ranks (core/sharded.py): the bond-capped sweep with an all-reduce of the Gram
+matrices, against the single-GPU sweep of the same tensor.  World size 1 in-process; world size 2 as two processes
+that share cuda:0 and talk through gloo (RCCL needs one device per rank: the 8-GPU run is the driver's)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+from imgcompressionmps_amd import NDMPS, _lib  # noqa: E402
+from imgcompressionmps_amd.core import sharded  # noqa: E402
+from imgcompressionmps_amd.core.ndmps import _plan_for  # noqa: E402
+from oracle.metrics import synthetic_mri  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _site_order(x):
+    """The site-order tensor of a C-order volume (the library's own reshape stage) and its site dims."""
+    lib = _lib.load()
+    plan = _plan_for(tuple(x.shape), 0)
+    src = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(DEV)
+    dense = torch.empty(plan.numel, dtype=torch.float32, device=DEV)
+    _lib.check(lib.ndmps_encode_permute(plan.handle, src.data_ptr(), dense.data_ptr(), 4, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return dense, [int(q) for q in plan.qubit_size]
+
+
+def _check_against_single_gpu(x, chi, rank, world, group=None):
+    dense, dims = _site_order(x)
+    n_local = dense.numel() // world
+    mine = dense[rank * n_local:(rank + 1) * n_local].clone()
+    mps = sharded.from_dense_sharded(mine, dims, max_bond=chi, group=group)
+    ref = NDMPS.from_tensor(x, max_bond=chi)
+    assert mps.bond_sizes() == ref.bond_sizes()
+    ref_dense = ref.mps.to_dense()
+    rec = sharded.local_dense(mps, rank, world)
+    want = ref_dense[rank * n_local:(rank + 1) * n_local]
+    rel = float((rec - want).norm() / want.norm())
+    assert rel <= 2e-5, rel
+    # the replicated MPS stands for the whole tensor
+    full = mps.to_dense()
+    assert float((full - ref_dense).norm() / ref_dense.norm()) <= 2e-5
+    err = float((full - dense).norm() / dense.norm())
+    err_ref = float((ref_dense - dense).norm() / dense.norm())
+    assert abs(err - err_ref) <= 1e-5 * max(err_ref, 1e-3)
+    return True
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device; the product has no CPU path")
+
+
+@pytest.mark.parametrize("shape,chi", [((64, 64, 64), 16), ((128, 128, 128), 32), ((32, 32, 16, 24), 12)])
+def test_sharded_sweep_world_size_1_equals_the_ordinary_sweep(shape, chi):
+    assert _check_against_single_gpu(synthetic_mri(shape, seed=5), chi, 0, 1)
+
+
+def test_sharded_sweep_rejects_bad_arguments():
+    dense, dims = _site_order(synthetic_mri((32, 32, 32), seed=1))
+    with pytest.raises(ValueError):
+        sharded.from_dense_sharded(dense, dims, max_bond=None)
+    with pytest.raises(ValueError):
+        sharded.from_dense_sharded(dense[:100], dims, max_bond=8)
+    with pytest.raises(ValueError):
+        sharded.from_dense_sharded(dense.double(), dims, max_bond=8)
+
+
+def _worker(rank, world, port, shape, chi, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, bool(_check_against_single_gpu(synthetic_mri(shape, seed=5), chi, rank, world))))
+    except Exception as exc:  # the assertion text travels back to the parent
+        q.put((rank, f"{type(exc).__name__}: {exc}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,chi", [((64, 64, 64), 16), ((128, 128, 128), 32)])
+def test_sharded_sweep_two_ranks_all_reduce_the_gram_matrices(shape, chi):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, chi, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)], results
