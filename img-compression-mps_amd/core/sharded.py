@@ -161,3 +161,67 @@ def local_dense(mps: DeviceMPS, rank: int, world: int):
             j += 1
         head = cur.reshape(1, rows, cur.shape[1]).contiguous()
         return DeviceMPS([head] + [c.to(torch.float32) for c in mps.cores[j:]]).to_dense()
+
+
+# ---------------------------------------------------------------- from blocks of the C-order volume
+# Site 0 of the encoding (utils/core.py: hierarchical_block_indexing) numbers the TOP-LEVEL blocks of the volume:
+# axis a is cut into f_0[a] pieces, the block (b_0, .., b_{D-1}) has digit ravel_multi_index(b, f_0), and inside a
+# block the remaining sites encode the block's own voxels with the factor lists of levels 1 .. L-1.  A rank that
+# owns the digits [r, r + 1) * d_0 / world therefore needs exactly those sub-boxes of the volume, and its rows of
+# the site-order tensor are the blocks' own site-order tensors, one after the other.
+def top_block_slices(shape, digit: int):
+    """Slices of the C-order volume that make up top-level block ``digit`` (0 <= digit < site_dims(shape)[0])."""
+    from ..utils import core as _core
+
+    fa, _ = _core.get_factorlist(tuple(int(s) for s in shape))
+    f0 = [int(f) for f in fa[0]]
+    if not 0 <= int(digit) < int(np.prod(f0)):
+        raise ValueError(f"top-level block {digit} outside [0, {int(np.prod(f0))})")
+    b = np.unravel_index(int(digit), f0)
+    sizes = [int(s) // f for s, f in zip(shape, f0)]
+    return tuple(slice(int(bi) * sz, (int(bi) + 1) * sz) for bi, sz in zip(b, sizes))
+
+
+def shard_from_blocks(blocks, shape, device=None):
+    """``blocks``: the top-level blocks a rank owns, in digit order (each a C-order sub-box
+    ``volume[top_block_slices(shape, digit)]``, NumPy or torch).  Returns the rank's rows of the site-order tensor
+    (fp32, device): every block goes through the library's reshape stage with the factor lists of levels 1 .. L-1."""
+    import torch
+
+    from ..utils import core as _core
+
+    lib = _lib.load()
+    _lib.require_device()
+    shape = tuple(int(s) for s in shape)
+    fa, _ = _core.get_factorlist(shape)
+    if fa.shape[0] < 2:
+        raise ValueError("a single-site encoding has no rows to shard")
+    sub = np.ascontiguousarray(fa[1:], dtype=np.int64)
+    sub_shape = tuple(int(v) for v in np.prod(sub, axis=0))
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    handle = C.c_void_p()
+    _lib.check(lib.ndmps_plan_create(C.byref(handle), len(sub_shape), _lib.i64_array(sub_shape), sub.shape[0],
+                                     sub.ctypes.data_as(_lib.p_i64)))
+    try:
+        n_sub = int(np.prod(sub_shape, dtype=np.int64))
+        out = torch.empty(len(blocks) * n_sub, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            for t, blk in enumerate(blocks):
+                src = blk if isinstance(blk, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(blk, dtype=np.float32))
+                if tuple(src.shape) != sub_shape:
+                    raise ValueError(f"block {t} has shape {tuple(src.shape)}, a top-level block of {shape} is {sub_shape}")
+                src = src.to(device=device, dtype=torch.float32).contiguous()
+                _lib.check(lib.ndmps_encode_permute(handle, src.data_ptr(), out[t * n_sub:].data_ptr(), 4, _lib.stream_ptr()))
+            torch.cuda.current_stream().synchronize()  # the plan's tables are freed below
+    finally:
+        lib.ndmps_plan_destroy(handle)
+    return out
+
+
+def from_volume_sharded(blocks, shape, max_bond, cutoff: float = 1e-10, group=None, device=None) -> DeviceMPS:
+    """The bond-capped MPS of ONE volume of ``shape`` held as top-level blocks across the ranks of ``group``: this
+    rank passes the blocks with digits ``[rank, rank + 1) * d_0 / world`` in order.  Replicated result."""
+    from ..utils import core as _core
+
+    dims = [int(q) for q in _core.site_dims(tuple(int(s) for s in shape))]
+    return from_dense_sharded(shard_from_blocks(blocks, shape, device), dims, max_bond, cutoff, group)

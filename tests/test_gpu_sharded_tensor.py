@@ -102,3 +102,31 @@ def test_sharded_sweep_two_ranks_all_reduce_the_gram_matrices(shape, chi):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)], results
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (48, 40, 36), (32, 32, 16, 24), (512, 680), (128, 128, 128)])
+def test_top_level_blocks_are_the_rows_of_the_site_order_tensor(shape):
+    """Bit-exact: encoding a rank's top-level blocks on their own gives its rows of the full site-order tensor."""
+    x = synthetic_mri(shape, seed=9) if len(shape) > 2 else np.random.default_rng(9).random(shape).astype(np.float32)
+    dense, dims = _site_order(x)
+    d0 = dims[0]
+    for world in [w for w in (1, 2, d0) if d0 % w == 0]:
+        step = d0 // world
+        for rank in range(world):
+            blocks = [x[sharded.top_block_slices(shape, d)] for d in range(rank * step, (rank + 1) * step)]
+            mine = sharded.shard_from_blocks(blocks, shape)
+            n_local = dense.numel() // world
+            assert torch.equal(mine, dense[rank * n_local:(rank + 1) * n_local]), (world, rank)
+    with pytest.raises(ValueError):
+        sharded.top_block_slices(shape, d0)
+
+
+def test_from_volume_sharded_equals_from_tensor():
+    shape, chi = (64, 64, 64), 16
+    x = synthetic_mri(shape, seed=2)
+    blocks = [x[sharded.top_block_slices(shape, d)] for d in range(8)]
+    mps = sharded.from_volume_sharded(blocks, shape, max_bond=chi)
+    ref = NDMPS.from_tensor(x, max_bond=chi)
+    assert mps.bond_sizes() == ref.bond_sizes()
+    a, b = mps.to_dense(), ref.mps.to_dense()
+    assert float((a - b).norm() / b.norm()) <= 2e-5
