@@ -204,3 +204,22 @@ def test_split_offsets_reproduce_the_reference_permutation(shape, n_sites_tail):
     rows = numel // n_cols
     want_row, want_col = flat.reshape(rows, n_cols)[:, 0], flat.reshape(rows, n_cols)[0, :]
     assert np.array_equal(flat.reshape(rows, n_cols), want_row[:, None] + want_col[None, :])  # additivity itself
+
+
+def test_top_block_slices_follow_the_first_site_of_the_encoding_map():
+    """core/sharded.py: top-level block `digit` holds exactly the voxels whose site-0 digit is `digit`
+    (pure host logic; the encoding map is the oracle's, pinned by the reference's golden vectors)."""
+    from imgcompressionmps_amd.core import sharded
+    from oracle import index_map as oim
+
+    for shape in [(8, 8), (12, 18), (16, 16, 16), (6, 10, 4), (4, 6, 2, 12)]:
+        sites, enc = oim.gen_encoding_map(shape)
+        digit0 = np.asarray(enc)[0] if np.asarray(enc).shape[0] == len(sites) else np.moveaxis(np.asarray(enc), -1, 0)[0]
+        seen = np.zeros(shape, dtype=int)
+        for d in range(int(sites[0])):
+            sl = sharded.top_block_slices(shape, d)
+            assert np.all(digit0[sl] == d)
+            seen[sl] += 1
+        assert np.all(seen == 1)
+        with pytest.raises(ValueError):
+            sharded.top_block_slices(shape, int(sites[0]))

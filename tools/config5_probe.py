@@ -26,3 +26,22 @@ for dt in (torch.float32, torch.bfloat16):
     print(f"{dt}: encode {1e3 * (t1 - t0):.1f} ms, reconstruct {1e3 * (t2 - t1):.1f} ms, {n / (t2 - t0) / 1e6:.0f} Mvoxels/s, "
           f"bonds {obj.bond_sizes()}, rel err {float((rec.float() - xi.float()).norm() / xi.float().norm()):.3e}")
     del obj, rec, xi
+
+# the same tensor through the row-sharded sweep (core/sharded.py) at world size 1: blocks -> rows -> per-site Gram,
+# eigen-solve, projection; the exchange step (all-reduce of the Gram matrix) is a no-op here
+from imgcompressionmps_amd.core import sharded  # noqa: E402
+from imgcompressionmps_amd.utils import core as hcore  # noqa: E402
+
+shape = tuple(x.shape)
+d0 = int(hcore.site_dims(shape)[0])
+blocks = [x[sharded.top_block_slices(shape, d)].contiguous() for d in range(d0)]
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mps = sharded.from_volume_sharded(blocks, shape, max_bond=128)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+ref = NDMPS.from_tensor(x, max_bond=128)
+a, b = mps.to_dense(), ref.mps.to_dense()
+print(f"sharded sweep, world 1: {1e3 * (t1 - t0):.1f} ms, site dims {[int(q) for q in hcore.site_dims(shape)]}, bonds {mps.bond_sizes()} "
+      f"(single-GPU sweep: {ref.bond_sizes()}), rel diff of the two MPS {float((a - b).norm() / b.norm()):.2e}")
