@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libndmps_hip.so")
 
-OK, EINVAL, EHIP, ENOCONV, EWORKSPACE = 0, -1, -2, -3, -4
+OK, EINVAL, EHIP, ENOCONV, EWORKSPACE, ETEAM = 0, -1, -2, -3, -4, -5
 
 i64 = C.c_int64
 p_i64 = C.POINTER(C.c_int64)
@@ -100,6 +100,11 @@ SIGNATURES = {
     "ndmps_syevd_topk_values_f64": (C.c_int, [C.c_int, vp, i64, p_i64, vp, i64, vp, i64, i64, vp, i64, vp]),
     "ndmps_syevd_topk_vectors_f64": (C.c_int, [C.c_int, p_i64, p_i64, i64, vp, i64, p_int, vp]),
     "ndmps_syevd_topk_vectors_auto_f64": (C.c_int, [C.c_int, p_i64, i64, C.c_double, vp, vp, i64, vp, vp, i64, vp]),
+    "ndmps_syevd_topk_recover_f64": (C.c_int, [C.c_int, p_i64, i64, vp, i64, p_int, vp]),
+    "ndmps_syevd_topk_set_team": (C.c_int, [C.c_int]),
+    "ndmps_syevd_topk_team_fallbacks": (i64, []),
+    "ndmps_syevd_topk_note_team_fallback": (C.c_int, []),
+    "ndmps_debug_inject_team_abort": (C.c_int, [C.c_int]),
     "ndmps_tt_sweep_pads_cores": (C.c_int, [C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_workspace_bytes": (i64, [C.c_int, C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
@@ -150,6 +155,11 @@ class NdmpsHipError(RuntimeError):
     pass
 
 
+class NdmpsTeamAbort(NdmpsHipError):
+    """A resident tridiagonalisation gave up waiting for its workgroups (NDMPS_ETEAM): the call's outputs are
+    invalid; the caller repeats it with the resident launch switched off (ndmps_syevd_topk_set_team(0))."""
+
+
 def load():
     """Load libndmps_hip.so (once).  Raises ImportError if it has not been built."""
     global _lib
@@ -176,6 +186,8 @@ def check(rc):
     msg = load().ndmps_last_error().decode("utf-8", "replace")
     if rc == EINVAL:
         raise ValueError(msg)
+    if rc == ETEAM:
+        raise NdmpsTeamAbort(f"libndmps_hip error {rc}: {msg}")
     raise NdmpsHipError(f"libndmps_hip error {rc}: {msg}")
 
 

@@ -132,6 +132,24 @@ def _checked_layout(header):
         numel *= d
     if bonds[0] != 1 or bonds[-1] != 1:
         raise ValueError("NDMPS container header: open boundary bonds must be 1")
+    # the remaining fields are read after the payload has been inflated: validated here as well, so that a crafted
+    # container fails with ValueError before anything is allocated
+    if not isinstance(header.get("mode"), str):  # any string, as in the reference (ndmps.py:62, :150-153)
+        raise ValueError("NDMPS container header: mode must be a string")
+    if not isinstance(header.get("norm"), bool):
+        raise ValueError("NDMPS container header: norm must be a boolean")
+    if not isinstance(header.get("dim"), int) or isinstance(header.get("dim"), bool) or header["dim"] != len(shape):
+        raise ValueError("NDMPS container header: dim must equal the number of tensor axes")
+    nv = header.get("norm_value", None)
+    if nv is not None and (isinstance(nv, bool) or not isinstance(nv, (int, float))):
+        raise ValueError("NDMPS container header: norm_value must be a number or null")
+    if name not in ("float32", "float64"):
+        bounds = header.get("bounds")
+        ok = isinstance(bounds, list) and len(bounds) == len(dims) and all(
+            isinstance(b, list) and len(b) == 2 and all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in b)
+            for b in bounds)
+        if not ok:
+            raise ValueError("NDMPS container header: quantised cores need one [min, max] pair per core")
     left = 1
     for i, d in enumerate(dims[:-1]):
         left *= d

@@ -181,18 +181,29 @@ class _GroupState:
     def __init__(self, objs, partial, count, n_cores, stream):
         import weakref
 
+        import threading
+
         self.refs = [weakref.ref(o) for o in objs]
         self.partial, self.count, self.n_cores, self.stream = partial, count, n_cores, stream
+        self.device = partial.device
         self.done = False
+        self._lock = threading.Lock()
 
     def resolve(self):
-        if self.done:
-            return
-        self.done = True
+        # one collector at a time (the ctypes call releases the GIL): a second reader waits here and finds the values
+        # stored; `done` is set only once they are, and a failing collect leaves the state unresolved for the next try
+        with self._lock:
+            if self.done:
+                return
+            self._collect()
+            self.done = True
+
+    def _collect(self):
         lib = _lib.load()
         out = (C.c_float * (2 * self.count))()
         ss = (C.c_double * self.count)()
-        _lib.check(lib.ndmps_minmax_collect(self.count, self.partial.data_ptr(), out, ss, self.stream))
+        with _torch().cuda.device(self.device):  # the stream handle belongs to this device
+            _lib.check(lib.ndmps_minmax_collect(self.count, self.partial.data_ptr(), out, ss, self.stream))
         mm = np.frombuffer(out, dtype=np.float32).astype(np.float64).reshape(-1, self.n_cores, 2)
         ssn = np.frombuffer(ss, dtype=np.float64)
         for b, ref in enumerate(self.refs):
@@ -346,12 +357,30 @@ class NDMPS:
         under the decode instead of in front of it); the reconstructions (device tensors) equal
         ``NDMPS.to_tensors(objects, as_torch=True)``.
         """
-        torch = _torch()
         _lib.require_device()
         lib = _lib.load()
         tensors = list(tensors)
         if not tensors:
             return ([], []) if reconstruct else []
+        args = (tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct)
+        try:
+            return cls._encode_group(*args)
+        except _lib.NdmpsTeamAbort:
+            # a resident tridiagonalisation gave up waiting for its workgroups (the GPU is shared with something that
+            # holds the compute units): the inputs are untouched, so the group is encoded again on the per-column
+            # launches, whose only synchronisation is the kernel boundary; counted in ndmps_syevd_topk_team_fallbacks
+            _lib.check(lib.ndmps_syevd_topk_note_team_fallback())
+            was = lib.ndmps_syevd_topk_set_team(0)
+            try:
+                return cls._encode_group(*args)
+            finally:
+                lib.ndmps_syevd_topk_set_team(was)
+
+    @classmethod
+    def _encode_group(cls, tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct):
+        """One lockstep group through norm / DCT / reshape stage / sweep (/ decode): the body of from_tensors."""
+        torch = _torch()
+        lib = _lib.load()
         first = tensors[0]
         if device is None:
             device = first.device if isinstance(first, torch.Tensor) and first.is_cuda else "cuda"

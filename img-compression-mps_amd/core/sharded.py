@@ -85,10 +85,33 @@ def from_dense_sharded(local_dense, dims, max_bond, cutoff: float = 1e-10, group
             ebytes = int(lib.ndmps_syevd_topk_workspace_bytes(n, 1, k_max))
             ews = torch.empty(ebytes, dtype=torch.uint8, device=device)
             sizes = _lib.i64_array([n])
-            _lib.check(lib.ndmps_syevd_topk_values_f64(1, g.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(), n,
-                                                       k_max, ews.data_ptr(), ebytes, stream))
+            def values():
+                _lib.check(lib.ndmps_syevd_topk_values_f64(1, g.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(), n,
+                                                           k_max, ews.data_ptr(), ebytes, stream))
+
+            values()
+            # the host reads the eigenvalues next: a resident tridiagonalisation that gave up is redone on the column
+            # launches here.  The two routes differ in the last bits, and the ranks must keep identical cores, so a
+            # recovery on any rank makes every rank take the column launches for this site.
+            recovered = C.c_int(0)
+            _lib.check(lib.ndmps_syevd_topk_recover_f64(1, sizes, k_max, ews.data_ptr(), ebytes, C.byref(recovered), stream))
+            if world > 1:
+                flag = torch.tensor([recovered.value], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                if int(flag.item()) and not recovered.value:
+                    was = lib.ndmps_syevd_topk_set_team(0)
+                    try:
+                        values()
+                    finally:
+                        lib.ndmps_syevd_topk_set_team(was)
             sigma = np.sqrt(np.maximum(w.cpu().numpy()[:k_max], 0.0))
             k = _kept(sigma, cutoff, chi)
+            if world > 1:
+                # every rank holds the same eigenvalues as long as the all-reduce is replicated bit for bit; the rank
+                # is what fixes the shapes of everything that follows, so it is agreed on explicitly
+                kt = torch.tensor([k], dtype=torch.int64, device=device)
+                dist.broadcast(kt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                k = int(kt.item())
             status = (C.c_int * 1)()
             _lib.check(lib.ndmps_syevd_topk_vectors_f64(1, sizes, _lib.i64_array([k]), k_max, ews.data_ptr(), ebytes, status,
                                                         stream))
@@ -101,26 +124,51 @@ def from_dense_sharded(local_dense, dims, max_bond, cutoff: float = 1e-10, group
             carried, chi_r = nxt, k
             i -= 1
         # ---- the rest on every rank: gather the carried matrix (rows of sites 0..i, chi_r columns)
-        if world > 1:
-            parts = [torch.empty_like(carried) for _ in range(world)]
-            dist.all_gather(parts, carried.contiguous(), group=group)
-            full = torch.cat(parts)
-        else:
-            full = carried.clone()  # the ordinary sweep works in place
+        # what is left runs replicated: the gathered carried matrix plus the ordinary sweep's workspace must fit
         head = dims[:i] + [dims[i] * chi_r]     # the carried matrix as a tensor whose last "site" is (d_i, chi_{i+1})
+        wsb = C.c_int64()
+        _lib.check(lib.ndmps_tt_layout(len(head), _lib.i64_array(head), chi, (C.c_int64 * (len(head) + 1))(),
+                                       (C.c_int64 * (len(head) + 1))(), (C.c_int64 * (len(head) + 1))(), C.byref(wsb)))
+        need = 2 * carried.numel() * world * 4 + int(wsb.value)
+        free, _total = torch.cuda.mem_get_info(device)
+        if need > free:
+            raise MemoryError(
+                f"the replicated part of the sharded sweep (sites 0..{i}: {carried.numel() * world} carried elements "
+                f"gathered on every rank + {int(wsb.value)} bytes of sweep workspace = {need} bytes) does not fit the "
+                f"{free} bytes free on {device}; use more ranks only if the left sites stay sharded (the loop stops "
+                f"sharding once a rank holds fewer than max(n_i, 256) rows)")
+        def gathered():
+            if world > 1:
+                parts = [torch.empty_like(carried) for _ in range(world)]
+                dist.all_gather(parts, carried.contiguous(), group=group)
+                return torch.cat(parts)
+            return carried.clone()  # the ordinary sweep works in place
+
+        full = gathered()
         Lh = len(head)
         cdims = _lib.i64_array(head)
         max_bonds = (C.c_int64 * (Lh + 1))()
         core_off = (C.c_int64 * (Lh + 1))()
         spec_off = (C.c_int64 * (Lh + 1))()
-        wsb = C.c_int64()
         _lib.check(lib.ndmps_tt_layout(Lh, cdims, chi, max_bonds, core_off, spec_off, C.byref(wsb)))
         arena = torch.zeros(int(core_off[Lh]) + 64, dtype=torch.float32, device=device)
         ws = torch.empty(int(wsb.value), dtype=torch.uint8, device=device)
         bonds = (C.c_int64 * (Lh + 1))()
         spectra = (C.c_double * max(int(spec_off[Lh]), 1))()
-        _lib.check(lib.ndmps_tt_sweep_f32(full.data_ptr(), Lh, cdims, float(cutoff), chi, arena.data_ptr(), core_off, bonds,
-                                          spectra, spec_off, ws.data_ptr(), int(wsb.value), stream))
+        def sweep():
+            _lib.check(lib.ndmps_tt_sweep_f32(full.data_ptr(), Lh, cdims, float(cutoff), chi, arena.data_ptr(), core_off,
+                                              bonds, spectra, spec_off, ws.data_ptr(), int(wsb.value), stream))
+
+        try:
+            sweep()
+        except _lib.NdmpsTeamAbort:  # the sweep overwrote its input: gather again, column launches this time
+            _lib.check(lib.ndmps_syevd_topk_note_team_fallback())
+            full = gathered()
+            was = lib.ndmps_syevd_topk_set_team(0)
+            try:
+                sweep()
+            finally:
+                lib.ndmps_syevd_topk_set_team(was)
         padded = bool(lib.ndmps_tt_sweep_pads_cores(Lh, cdims, chi))
         for j in range(Lh):
             k0, k1 = int(bonds[j]), int(bonds[j + 1])

@@ -73,13 +73,28 @@ __device__ __forceinline__ double from_f64<double>(double x) { return x; }
 // launch spans for bench.py's roofline (util.hip); slot ids
 constexpr int kSpanTridiagColumns = 1;
 constexpr int kSpanTridiagTeam = 2;
-constexpr int kSpanGram = 3;  // `bytes` of the span = flops
+constexpr int kSpanGram = 3;       // Gram launches that take the device-side turn (a lockstep group's raw Gram); `bytes` = flops
+constexpr int kSpanGramSmall = 4;  // every other batched Gram launch; `bytes` = flops
 void* span_begin(hipStream_t s);
 void span_end(void* begin, hipStream_t s, int slot, int64_t launches, int64_t bytes);
 
-// turns between streams for kernels that fill the GPU alone (util.hip)
+// turns between streams for kernels that fill the GPU alone (util.hip): begin() enqueues the acquire, end() (or the
+// destructor, on an early return) the release; the submission of a whole turn is atomic per device
 constexpr int kTurnTeam = 0, kTurnGram = 1;
-int turn_begin(hipStream_t s, int which);
-int turn_end(hipStream_t s, int which);
+class Turn {
+ public:
+  Turn(hipStream_t s, int which) : s_(s), which_(which) {}
+  ~Turn();
+  Turn(const Turn&) = delete;
+  Turn& operator=(const Turn&) = delete;
+  int begin();
+  int end();
+
+ private:
+  hipStream_t s_;
+  int which_;
+  void* dev_ = nullptr;  // per-device turn state while the turn is open
+  unsigned ticket_ = 0;
+};
 
 }  // namespace ndmps

@@ -351,13 +351,18 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
 // reads the two n-vectors back.  Exchange data moves with agent-scope atomic stores / loads (write-through,
 // never served from a stale L2 line of another XCD); release / acquire fences order them around the counter.
 //
-// The workgroups of a matrix (its team, 16 at n = 512) must be resident together.  The dispatcher places
-// workgroups in grid order and a team is 16 consecutive ones, so the teams at the front of the grid are always
-// complete and their exit frees the slots the next ones wait for: a grid larger than the GPU is fine.  Two team
-// kernels from different streams could starve each other (each holding slots the other's partial teams wait
-// for), so the host chains them by an event: at most one is in flight per device.  Ordinary kernels sharing
-// the GPU end by themselves.  Every wait is bounded all the same: after kTeamSpinTicks the waiting workgroup
-// raises the team's abort flag, every member leaves at its next wait and status 2 reaches the host.
+// The workgroups of a matrix (its team, 16 at n = 512) must be resident together.  Liveness rests on three
+// invariants kept by the host side (ndmps_syevd_topk_values_f64):
+//   * a launch holds at most `team_slots()` workgroups (occupancy x compute units, at most two per CU): every team
+//     of a launch is resident whatever order the dispatcher places workgroups in; larger batches go in several
+//     launches;
+//   * at most one team launch is in flight per device: the turn is taken ON THE DEVICE (ndmps::Turn, util.hip: a
+//     one-thread kernel in front spins on a lock word, one behind gives it back), because two team kernels from
+//     different streams could each hold slots the other's partial teams wait for.  Ordinary kernels sharing the
+//     GPU end by themselves;
+//   * every wait is bounded: after kTeamSpinTicks (3 s) the waiting workgroup raises the team's abort flag, every
+//     member leaves at its next wait and status 2 reaches the host, which re-runs the reduction on the column
+//     launches (trd_column_kernel) and counts the event (ndmps_syevd_topk_team_fallbacks).
 //
 // Arithmetic: the prologue and the per-element update are those of trd_column_kernel (same redundant,
 // bit-identical O(n) part in every workgroup); only the association of the column sums differs (rows are
@@ -1380,7 +1385,7 @@ __global__ void __launch_bounds__(512) trd_ortho_kernel(TrdDesc* __restrict__ de
     if constexpr (FAST) {
       // ---- fast path: blocked Cholesky + explicit L^-1 in LDS, then Z <- Z L^-T as a product on the MFMA
       double* Li = lds + k16 * ldl;
-      if (!chol_inv_blocked(Ls, Li, k16, k, ldl, tid) && tid == 0) d.status = 1;
+      if (!chol_inv_blocked(Ls, Li, k16, k, ldl, tid) && tid == 0 && d.status != 2) d.status = 1;
       if (tid == 0) stamp[4 + 3 * pass] = wall_clock64();
       // one wave per 16-row block of Z: all its operands are read before anything is written back
       for (int rt = wave; rt * 16 < n; rt += 8) {
@@ -1426,7 +1431,7 @@ __global__ void __launch_bounds__(512) trd_ortho_kernel(TrdDesc* __restrict__ de
           Ls[tid * ldl + jc] = tid == jc ? piv * rs : v * rs;
         } else {  // breakdown: two columns parallel to working precision
           Ls[tid * ldl + jc] = tid == jc ? 1.0 : 0.0;
-          if (tid == jc) d.status = 1;
+          if (tid == jc && d.status != 2) d.status = 1;
         }
       }
       __syncthreads();
@@ -1714,8 +1719,23 @@ __global__ void trd_setk_kernel(TrdDesc* __restrict__ desc, RankChunk chunk, int
   const int t = threadIdx.x;
   if (t < count) {
     desc[base + t].k = chunk.v[t];
-    if (desc[base + t].status != 2) desc[base + t].status = 0;  // 2: the team kernel gave up (sticky)
+    // 2: the team kernel gave up (sticky until ndmps_syevd_topk_recover_f64 has re-run the reduction)
+    if (desc[base + t].status != 2) desc[base + t].status = 0;
   }
+}
+__global__ void trd_clear_status_kernel(TrdDesc* __restrict__ desc, int batch, TeamSync* __restrict__ sync) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < batch) {
+    desc[b].status = 0;
+    sync[b].count = 0;
+    sync[b].abort = 0;
+  }
+}
+
+// Test hook (ndmps_debug_inject_team_abort): what an aborted team launch leaves behind, without the 3 s wait
+__global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < batch) desc[b].status = 2;
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1833,14 +1853,19 @@ int team_slots(int& slots) {
 }
 
 // At most one team kernel in flight per device (see trd_team_kernel); the turn is taken on the device
-// (ndmps::turn_begin / turn_end, util.hip).
+// (ndmps::Turn, util.hip).
 template <typename F>
 int team_launch(hipStream_t s, F&& launch) {
-  NDMPS_TRY(ndmps::turn_begin(s, ndmps::kTurnTeam));
+  ndmps::Turn turn(s, ndmps::kTurnTeam);
+  NDMPS_TRY(turn.begin());
   launch();
-  NDMPS_TRY(ndmps::turn_end(s, ndmps::kTurnTeam));
-  return NDMPS_OK;
+  return turn.end();
 }
+
+// the resident launch may be switched off per host thread (the fallback after an abort runs the column launches)
+thread_local int g_team_off = 0;
+std::atomic<long long> g_team_fallbacks{0};
+std::atomic<int> g_inject_abort{0};
 
 int trd_check_sizes(int batch, const int64_t* h_n, int64_t& n_max) {
   NDMPS_REQUIRE(batch >= 1 && batch <= 4096, "batch=%d outside [1, 4096]", batch);
@@ -1850,6 +1875,85 @@ int trd_check_sizes(int batch, const int64_t* h_n, int64_t& n_max) {
     NDMPS_REQUIRE(h_n[b] >= 1 && h_n[b] <= kMaxN, "eigen size n=%lld outside [1, %d]", (long long)h_n[b], kMaxN);
     n_max = std::max(n_max, h_n[b]);
   }
+  return NDMPS_OK;
+}
+
+// Tridiagonalisation of every matrix named by the descriptors (resident launch for orders <= 512 unless switched
+// off, column launches otherwise), the last kTail columns in LDS, then the min(k_max, n) largest eigenvalues.
+int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t k_max, const TrdLayout& l, const TrdWork& w,
+                          TrdDesc* desc, hipStream_t s) {
+  const unsigned B = (unsigned)batch;
+  const int load_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * l.lda, 256), 512);
+  hipLaunchKernelGGL(trd_load_kernel, dim3(load_grid, B), dim3(256), 0, s, desc, w);
+  // narrow column blocks while the grid stays below ~2 workgroups per CU (see trd_column_kernel)
+  const bool narrow = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= 2 * ndmps::kNumCU && !getenv("NDMPS_TRD_WIDE");
+  const int W = (int)ndmps::ceil_div(n_max, narrow ? 8 : 32);
+  const size_t col_lds = (size_t)n_max * sizeof(RowVec);
+  void (*column)(const TrdDesc*, TrdWork, int);
+  if (narrow)
+    column = n_max <= 512    ? trd_column_kernel<2, 8>
+             : n_max <= 1024 ? trd_column_kernel<4, 8>
+             : n_max <= 2048 ? trd_column_kernel<8, 8>
+                             : trd_column_kernel<16, 8>;
+  else
+    column = n_max <= 512    ? trd_column_kernel<2, 32>
+             : n_max <= 1024 ? trd_column_kernel<4, 32>
+             : n_max <= 2048 ? trd_column_kernel<8, 32>
+                             : trd_column_kernel<16, 32>;
+  // orders <= 512: one resident launch for all columns (trd_team_kernel; 2.2 ms for 1 .. 16 matrices of order
+  // 512, 2.5 ms for 32, against 2.4 / 3.8 / 5.7 ms of column launches); NDMPS_TRD_NO_TEAM=1 keeps the column
+  // launches (A/B timing, tests of that path)
+  const bool team = n_max <= 512 && n_max > kTail && !getenv("NDMPS_TRD_NO_TEAM") && !g_team_off;
+  void* span = ndmps::span_begin(s);
+  int64_t span_bytes = 0;  // algorithmic: every trailing element read once and written once per column
+  if (team) {
+    // a launch never holds more workgroups than the device keeps resident at once: no team then depends on the
+    // order in which the dispatcher places workgroups (larger batches go in several launches)
+    int slots = 0;
+    NDMPS_TRY(team_slots(slots));
+    // one to four matrices: 8-column blocks (64 workgroups per order-512 matrix, one per CU)
+    const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= slots && !getenv("NDMPS_TRD_TEAM_WIDE");
+    const int team_size = (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
+    const int per_launch = std::max(1, slots / team_size);
+    int inject = g_inject_abort.load();
+    while (inject > 0 && !g_inject_abort.compare_exchange_weak(inject, inject - 1)) {
+    }
+    if (inject > 0) {
+      hipLaunchKernelGGL(trd_inject_abort_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch);
+    } else
+    NDMPS_TRY(team_launch(s, [&]() {
+      static std::atomic<unsigned> epoch_counter{1};
+      // exchange without meetings (tagged records) while every workgroup has a CU's SIMDs to itself: 3-4 % faster
+      // for up to 16 order-512 matrices; with two workgroups per CU the polls of the waiting one get in the way of
+      // the working one and the counter is as fast (2.49 vs 2.53 ms for 32 matrices).  Environment: A/B.
+      const bool tagged = getenv("NDMPS_TRD_TEAM_COUNTER") ? false
+                          : getenv("NDMPS_TRD_TEAM_TAGGED") ? true
+                                                            : (int64_t)std::min(per_launch, batch) * team_size <= slots / 2;
+      for (int b0 = 0; b0 < batch; b0 += per_launch) {
+        const unsigned epoch = epoch_counter.fetch_add(1);
+        const dim3 grid((unsigned)team_size, (unsigned)std::min(per_launch, batch - b0));
+        if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, w, b0, epoch);
+        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, w, b0, epoch);
+        else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, w, b0, epoch);
+      }
+    }));
+    // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
+    for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
+    ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, span_bytes);
+  } else {
+    for (int j = 0; j < n_max - kTail; ++j) {
+      hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
+      if (span)
+        for (int b = 0; b < batch; ++b)
+          if (j < h_n[b] - kTail) span_bytes += 2 * 8 * (h_n[b] - j - 1) * (h_n[b] - j - 1);
+    }
+    ndmps::span_end(span, s, ndmps::kSpanTridiagColumns, std::max<int64_t>(n_max - kTail, 0), span_bytes);
+  }
+  hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
+  const int kk = (int)std::min(k_max, n_max);
+  hipLaunchKernelGGL(trd_bisect_kernel, dim3(ndmps::ceil_div(kk, 4), B), dim3(256),
+                     (size_t)ndmps::round_up(n_max, 16) * 16, s, desc, w, kk);
+  NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }
 
@@ -1904,73 +2008,7 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
     }
     hipLaunchKernelGGL(trd_setdesc_kernel, dim3(1), dim3(kDescChunk), 0, s, desc, chunk, base, count, w.sync);
   }
-  const unsigned B = (unsigned)batch;
-  const int load_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * l.lda, 256), 512);
-  hipLaunchKernelGGL(trd_load_kernel, dim3(load_grid, B), dim3(256), 0, s, desc, w);
-  // narrow column blocks while the grid stays below ~2 workgroups per CU (see trd_column_kernel)
-  const bool narrow = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= 2 * ndmps::kNumCU && !getenv("NDMPS_TRD_WIDE");
-  const int W = (int)ndmps::ceil_div(n_max, narrow ? 8 : 32);
-  const size_t col_lds = (size_t)n_max * sizeof(RowVec);
-  void (*column)(const TrdDesc*, TrdWork, int);
-  if (narrow)
-    column = n_max <= 512    ? trd_column_kernel<2, 8>
-             : n_max <= 1024 ? trd_column_kernel<4, 8>
-             : n_max <= 2048 ? trd_column_kernel<8, 8>
-                             : trd_column_kernel<16, 8>;
-  else
-    column = n_max <= 512    ? trd_column_kernel<2, 32>
-             : n_max <= 1024 ? trd_column_kernel<4, 32>
-             : n_max <= 2048 ? trd_column_kernel<8, 32>
-                             : trd_column_kernel<16, 32>;
-  // orders <= 512: one resident launch for all columns (trd_team_kernel; 2.2 ms for 1 .. 16 matrices of order
-  // 512, 2.5 ms for 32, against 2.4 / 3.8 / 5.7 ms of column launches); NDMPS_TRD_NO_TEAM=1 keeps the column
-  // launches (A/B timing, tests of that path)
-  const bool team = n_max <= 512 && n_max > kTail && !getenv("NDMPS_TRD_NO_TEAM");
-  void* span = ndmps::span_begin(s);
-  int64_t span_bytes = 0;  // algorithmic: every trailing element read once and written once per column
-  if (team) {
-    // a launch never holds more workgroups than the device keeps resident at once: no team then depends on the
-    // order in which the dispatcher places workgroups (larger batches go in several launches)
-    int slots = 0;
-    NDMPS_TRY(team_slots(slots));
-    // one to four matrices: 8-column blocks (64 workgroups per order-512 matrix, one per CU)
-    const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= slots && !getenv("NDMPS_TRD_TEAM_WIDE");
-    const int team_size = (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
-    const int per_launch = std::max(1, slots / team_size);
-    NDMPS_TRY(team_launch(s, [&]() {
-      static std::atomic<unsigned> epoch_counter{1};
-      // exchange without meetings (tagged records) while every workgroup has a CU's SIMDs to itself: 3-4 % faster
-      // for up to 16 order-512 matrices; with two workgroups per CU the polls of the waiting one get in the way of
-      // the working one and the counter is as fast (2.49 vs 2.53 ms for 32 matrices).  Environment: A/B.
-      const bool tagged = getenv("NDMPS_TRD_TEAM_COUNTER") ? false
-                          : getenv("NDMPS_TRD_TEAM_TAGGED") ? true
-                                                            : (int64_t)std::min(per_launch, batch) * team_size <= slots / 2;
-      for (int b0 = 0; b0 < batch; b0 += per_launch) {
-        const unsigned epoch = epoch_counter.fetch_add(1);
-        const dim3 grid((unsigned)team_size, (unsigned)std::min(per_launch, batch - b0));
-        if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, w, b0, epoch);
-        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, w, b0, epoch);
-        else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, w, b0, epoch);
-      }
-    }));
-    // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
-    for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
-    ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, span_bytes);
-  } else {
-    for (int j = 0; j < n_max - kTail; ++j) {
-      hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
-      if (span)
-        for (int b = 0; b < batch; ++b)
-          if (j < h_n[b] - kTail) span_bytes += 2 * 8 * (h_n[b] - j - 1) * (h_n[b] - j - 1);
-    }
-    ndmps::span_end(span, s, ndmps::kSpanTridiagColumns, std::max<int64_t>(n_max - kTail, 0), span_bytes);
-  }
-  hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
-  const int kk = (int)std::min(k_max, n_max);
-  hipLaunchKernelGGL(trd_bisect_kernel, dim3(ndmps::ceil_div(kk, 4), B), dim3(256),
-                     (size_t)ndmps::round_up(n_max, 16) * 16, s, desc, w, kk);
-  NDMPS_LAUNCH_CHECK();
-  return NDMPS_OK;
+  return trd_reduce_and_values(batch, h_n, n_max, k_max, l, w, desc, s);
 }
 
 namespace {
@@ -2075,5 +2113,61 @@ extern "C" int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));
     for (int b = 0; b < batch; ++b) h_status[b] = host[b].status;
   }
+  return NDMPS_OK;
+}
+
+// ---- the resident tridiagonalisation's way out (status 2: a team gave up waiting for its workgroups, see
+// trd_team_kernel).  The reduction works on a copy of G, so phase 1 can simply be done again on the column launches,
+// whose only synchronisation is the kernel boundary.
+//
+// ndmps_syevd_topk_recover_f64: call after ndmps_syevd_topk_values_f64 with the same batch / sizes / workspace when the
+// host is about to synchronise anyway (it reads the eigenvalues): waits for `stream`, and if any matrix carries
+// status 2 re-runs phase 1 for the whole batch without the resident launch (asynchronous again), counts the event and
+// sets *h_recovered.  Callers that never synchronise between the phases (..._vectors_auto_f64) see status 2 in
+// d_status at the end and repeat their sequence after ndmps_syevd_topk_set_team(0) (the sweep does: tt.hip).
+extern "C" int ndmps_syevd_topk_recover_f64(int batch, const int64_t* h_n, int64_t k_max, void* d_ws, int64_t ws_bytes,
+                                            int* h_recovered, ndmps_stream_t stream) {
+  int64_t n_max = 0;
+  NDMPS_TRY(trd_check_sizes(batch, h_n, n_max));
+  NDMPS_REQUIRE(k_max >= 1 && k_max <= kMaxK, "k_max=%lld outside [1, %d]", (long long)k_max, kMaxK);
+  const TrdLayout l = trd_layout(n_max, batch, std::min(k_max, n_max));
+  if (d_ws == nullptr || ws_bytes < l.total) {
+    ndmps::set_error("syevd_topk workspace too small: %lld < %lld", (long long)ws_bytes, (long long)l.total);
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  TrdWork w = trd_work(l, d_ws);
+  TrdDesc* desc = (TrdDesc*)((char*)d_ws + l.off_desc);
+  std::vector<TrdDesc> host(batch);
+  NDMPS_CHECK_HIP(hipMemcpyAsync(host.data(), desc, sizeof(TrdDesc) * batch, hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  bool aborted = false;
+  for (int b = 0; b < batch; ++b) aborted = aborted || host[b].status == 2;
+  if (h_recovered) *h_recovered = aborted ? 1 : 0;
+  if (!aborted) return NDMPS_OK;
+  g_team_fallbacks.fetch_add(1);
+  hipLaunchKernelGGL(trd_clear_status_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch, w.sync);
+  g_team_off += 1;
+  const int rc = trd_reduce_and_values(batch, h_n, n_max, k_max, l, w, desc, s);
+  g_team_off -= 1;
+  return rc;
+}
+// Per host thread: 0 switches the resident launch off (column launches for every order), 1 back on; returns the
+// previous setting.  NDMPS_TRD_NO_TEAM=1 in the environment does the same for the whole process.
+extern "C" int ndmps_syevd_topk_set_team(int enabled) {
+  const int was = g_team_off ? 0 : 1;
+  g_team_off = enabled ? 0 : 1;
+  return was;
+}
+// number of times a resident launch was given up and its work redone on the column launches (whole process)
+extern "C" int64_t ndmps_syevd_topk_team_fallbacks(void) { return g_team_fallbacks.load(); }
+extern "C" int ndmps_syevd_topk_note_team_fallback(void) {  // for callers that redo their own sequence
+  g_team_fallbacks.fetch_add(1);
+  return NDMPS_OK;
+}
+// Test hook: the next `launches` resident launches are replaced by what an aborted one leaves behind (status 2 in
+// every descriptor, the reduction not done), without the 3 s wait.
+extern "C" int ndmps_debug_inject_team_abort(int launches) {
+  g_inject_abort.store(launches > 0 ? launches : 0);
   return NDMPS_OK;
 }

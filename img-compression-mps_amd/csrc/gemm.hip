@@ -1397,7 +1397,8 @@ int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int6
   // a launch that fills the GPU for milliseconds (a lockstep group's raw Gram) takes its turn with those of other
   // streams: two of them at once gain nothing (both MFMA-bound) and keep each other's groups in phase
   const bool turn = (int64_t)batch * g.slots >= 4096 && !getenv("NDMPS_GRAM_NO_TURN");
-  if (turn) NDMPS_TRY(ndmps::turn_begin(s, ndmps::kTurnGram));
+  ndmps::Turn gram_turn(s, ndmps::kTurnGram);
+  if (turn) NDMPS_TRY(gram_turn.begin());
   void* span = ndmps::span_begin(s);
   for (int base = 0; base < batch; base += kGram128MaxBatch) {
     const int count = std::min(kGram128MaxBatch, batch - base);
@@ -1411,8 +1412,9 @@ int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int6
                        partial + (int64_t)base * g.slots * 16384, g, vec_ok, d_row_off, d_col_off);
   }
   // algorithmic work of the span: the upper triangle incl. the diagonal, 2 flops per product
-  ndmps::span_end(span, s, ndmps::kSpanGram, (batch + kGram128MaxBatch - 1) / kGram128MaxBatch, (int64_t)batch * m * n * (n + 1));
-  if (turn) NDMPS_TRY(ndmps::turn_end(s, ndmps::kTurnGram));
+  ndmps::span_end(span, s, turn ? ndmps::kSpanGram : ndmps::kSpanGramSmall, (batch + kGram128MaxBatch - 1) / kGram128MaxBatch,
+                  (int64_t)batch * m * n * (n + 1));
+  NDMPS_TRY(gram_turn.end());
   hipLaunchKernelGGL(gram128_reduce_kernel, dim3(g.n_off + g.n_diag, 64, batch), dim3(256), 0, s, partial, g, d_G, stride_G, n,
                      d_perm);
   NDMPS_LAUNCH_CHECK();

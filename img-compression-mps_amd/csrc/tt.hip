@@ -573,12 +573,27 @@ inline int project_src(const __bf16*, int64_t, int64_t, int64_t, const SweepSour
 
 // status of the direct solver for one matrix (eig_tridiag.hip): 1 = Cholesky breakdown, 2 = a team gave up waiting
 inline int solver_failed(int site, int volume, int status) {
-  if (status == 2)
+  if (status == 2) {
     ndmps::set_error("site %d, volume %d: the resident tridiagonalisation gave up waiting for its workgroups (3 s; is the "
-                     "GPU shared with another process?); NDMPS_TRD_NO_TEAM=1 selects the column launches", site, volume);
-  else
-    ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", site, volume);
+                     "GPU shared with another process?); repeat the sweep after ndmps_syevd_topk_set_team(0)", site, volume);
+    return NDMPS_ETEAM;
+  }
+  ndmps::set_error("site %d, volume %d: eigenvector block lost rank in the orthonormalisation", site, volume);
   return NDMPS_ENOCONV;
+}
+
+// A sweep whose input is still intact (the fused one reads the volumes in place) repeats itself on the column
+// launches when a resident tridiagonalisation gave up (NDMPS_ETEAM); the others hand the code to the caller, who
+// owns the site-order copy the sweep has overwritten.
+template <typename F>
+int retry_without_team(F&& sweep) {
+  int rc = sweep();
+  if (rc != NDMPS_ETEAM) return rc;
+  (void)ndmps_syevd_topk_note_team_fallback();
+  const int was = ndmps_syevd_topk_set_team(0);
+  rc = sweep();
+  (void)ndmps_syevd_topk_set_team(was);
+  return rc;
 }
 
 template <typename T>
@@ -662,10 +677,12 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       for (int b = 0; b < batch; ++b) kept[b] = k_cap;
       return NDMPS_OK;
     }
-    if (topk)
+    if (topk) {
       NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
                                             ev_ws_bytes, s));
-    else
+      // the host waits for the eigenvalues anyway: a resident launch that gave up is redone on the column launches
+      NDMPS_TRY(ndmps_syevd_topk_recover_f64(batch, eig_n.data(), k_cap, ev_ws, ev_ws_bytes, nullptr, s));
+    } else
       NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(sizeof(T) == 8),
                                                ev_ws, ev_ws_bytes, &sweeps, s));
     NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
@@ -1080,8 +1097,10 @@ extern "C" int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h
                                                 int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_row_off && d_col_off && d_col_perm && n_cols >= 1, "NULL permutation table");
   SweepSource src{d_row_off, d_col_off, d_col_perm, n_cols};
-  return sweep_impl<float>(batch, (float* const*)h_volume, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets,
-                           h_bonds_out, h_spectra, h_spec_offsets, d_ws, ws_bytes, stream, &src);
+  return retry_without_team([&]() {
+    return sweep_impl<float>(batch, (float* const*)h_volume, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets,
+                             h_bonds_out, h_spectra, h_spec_offsets, d_ws, ws_bytes, stream, &src);
+  });
 }
 
 // bf16 storage: the site-order tensors, the carried matrices and the cores are bf16 in HBM; Gram matrices,

@@ -189,48 +189,86 @@ extern "C" int ndmps_profile_collect(int slot, double* h_ms, int64_t* h_launches
 // between streams ON THE DEVICE: a one-thread kernel in front spins on a lock word until it owns it, a one-thread
 // kernel behind gives it back.  The spinner holds one wave slot and a handful of registers, so the owner's kernels
 // always fit beside it, and whichever stream gets there first runs first (an event chain would follow the order in
-// which the HOST enqueues).  Bounded like every wait here: after 3 s the turn is taken regardless.
+// which the HOST enqueues).
+//
+// Streams may share a hardware queue (the runtime has 4 by default; ndmps_streams_create hands out shared ones when
+// more groups are asked for, and a caller's own stream is never measured).  Packets of one queue run in order, so a
+// spinner that landed BETWEEN another stream's acquire and release in a shared queue would wait for a release that
+// sits behind it.  Hence a turn [acquire, kernels, release] is SUBMITTED ATOMICALLY: one host mutex per device is held
+// from turn begin to turn end, for every kind of turn (two mutexes would still allow a cycle through two locks).  In
+// any queue an owner's release then has only its own acquire and its own kernels in front of it, which end by
+// themselves, so every spinner is released in finite time whatever the stream-to-queue map is.
+// The lock word holds the owner's ticket: a spinner that gave up after kTurnSpinTicks (bounded like every wait here)
+// runs unowned and its release leaves the real owner's lock alone.
 namespace {
 constexpr long long kTurnSpinTicks = 300000000LL;  // 3 s of the 100 MHz wall clock
-__global__ void turn_acquire_kernel(unsigned* __restrict__ lock) {
+__global__ void turn_acquire_kernel(unsigned* __restrict__ lock, unsigned ticket) {
   const long long t0 = wall_clock64();
-  while (atomicCAS(lock, 0u, 1u) != 0u) {
+  while (atomicCAS(lock, 0u, ticket) != 0u) {
     if (wall_clock64() - t0 > kTurnSpinTicks) break;
     __builtin_amdgcn_s_sleep(8);
   }
 }
-__global__ void turn_release_kernel(unsigned* __restrict__ lock) { atomicExch(lock, 0u); }
+__global__ void turn_release_kernel(unsigned* __restrict__ lock, unsigned ticket) { atomicCAS(lock, ticket, 0u); }
 
-int turn_word(int which, unsigned** word) {
-  static std::mutex mu;
-  static unsigned* base[64] = {};
+struct TurnDevice {
+  unsigned* base = nullptr;  // 256 bytes per device, once: the only allocation outside ndmps_plan_create
+  std::mutex submit;         // held while a turn is being enqueued
+  unsigned next_ticket = 1;
+};
+TurnDevice g_turn[64];
+std::mutex g_turn_alloc;
+
+int turn_device(TurnDevice** out) {
   int dev = 0;
   NDMPS_CHECK_HIP(hipGetDevice(&dev));
-  NDMPS_REQUIRE(dev >= 0 && dev < 64 && which >= 0 && which < 4, "device index %d outside [0, 64)", dev);
-  std::lock_guard<std::mutex> guard(mu);
-  if (!base[dev]) {  // 256 bytes per device, once: the only allocation outside ndmps_plan_create
-    NDMPS_CHECK_HIP(hipMalloc((void**)&base[dev], 256));
-    NDMPS_CHECK_HIP(hipMemset(base[dev], 0, 256));
+  NDMPS_REQUIRE(dev >= 0 && dev < 64, "device index %d outside [0, 64)", dev);
+  TurnDevice& td = g_turn[dev];
+  {
+    std::lock_guard<std::mutex> guard(g_turn_alloc);
+    if (!td.base) {
+      NDMPS_CHECK_HIP(hipMalloc((void**)&td.base, 256));
+      NDMPS_CHECK_HIP(hipMemset(td.base, 0, 256));
+    }
   }
-  *word = base[dev] + 16 * which;  // 64 bytes apart
+  *out = &td;
   return NDMPS_OK;
 }
 }  // namespace
 
 namespace ndmps {
-int turn_begin(hipStream_t s, int which) {
-  unsigned* word = nullptr;
-  NDMPS_TRY(turn_word(which, &word));
-  hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(1), 0, s, word);
-  NDMPS_LAUNCH_CHECK();
+Turn::~Turn() { (void)end(); }
+
+int Turn::begin() {
+  if (dev_) return NDMPS_OK;
+  NDMPS_REQUIRE(which_ >= 0 && which_ < 4, "turn kind %d outside [0, 4)", which_);
+  TurnDevice* td = nullptr;
+  NDMPS_TRY(turn_device(&td));
+  td->submit.lock();
+  dev_ = td;
+  ticket_ = td->next_ticket++;
+  if (td->next_ticket == 0) td->next_ticket = 1;  // 0 means "free"
+  hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(1), 0, s_, td->base + 16 * which_, ticket_);  // words 64 B apart
+  if (hipGetLastError() != hipSuccess) {
+    dev_ = nullptr;
+    td->submit.unlock();
+    set_error("turn_acquire_kernel launch failed");
+    return NDMPS_EHIP;
+  }
   return NDMPS_OK;
 }
-int turn_end(hipStream_t s, int which) {
-  unsigned* word = nullptr;
-  NDMPS_TRY(turn_word(which, &word));
-  hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(1), 0, s, word);
-  NDMPS_LAUNCH_CHECK();
+
+int Turn::end() {
+  if (!dev_) return NDMPS_OK;
+  TurnDevice* td = (TurnDevice*)dev_;
+  dev_ = nullptr;
+  hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(1), 0, s_, td->base + 16 * which_, ticket_);
+  const hipError_t e = hipGetLastError();
+  td->submit.unlock();
+  if (e != hipSuccess) {
+    set_error("turn_release_kernel launch failed: %s", hipGetErrorString(e));
+    return NDMPS_EHIP;
+  }
   return NDMPS_OK;
 }
 }  // namespace ndmps
-

@@ -31,6 +31,9 @@ extern "C" {
 #define NDMPS_EHIP (-2)     /* HIP runtime failure (maps to RuntimeError) */
 #define NDMPS_ENOCONV (-3)  /* eigen-solver did not converge */
 #define NDMPS_EWORKSPACE (-4) /* workspace too small */
+#define NDMPS_ETEAM (-5)    /* a resident tridiagonalisation gave up waiting for its workgroups (GPU shared with
+                             * something that holds the compute units): the call's outputs are invalid; repeat it
+                             * after ndmps_syevd_topk_set_team(0) (sweeps whose input is intact do so themselves) */
 
 typedef void* ndmps_stream_t;
 typedef struct ndmps_plan ndmps_plan_t;
@@ -49,9 +52,13 @@ int ndmps_device_count(void);
 int ndmps_streams_create(int n, void** h_streams, int* n_independent);
 int ndmps_streams_destroy(int n, void* const* h_streams);
 
-/* Launch spans for the roofline of bench.py: when enabled, the column launches of the direct eigen-solver
- * (slot 1) bracket themselves with HIP events on their own stream; collect sums device ms, launches and
- * algorithmic bytes of the spans recorded so far (and clears them).  No reference counterpart. */
+/* Launch spans for the roofline of bench.py: when enabled, the kernels bench.py prices bracket themselves with HIP
+ * events on the stream they are launched on and file the span under a slot: 1 = column launches of the direct
+ * eigen-solver (amount = algorithmic bytes), 2 = the resident tridiagonalisation (one span per launch sequence of a
+ * batch; bytes), 3 = the Gram launches that fill the GPU for milliseconds and take a device-side turn (a lockstep
+ * group's raw Gram; amount = FLOPS m n (n + 1) per matrix), 4 = every other batched Gram launch (flops).  collect
+ * sums device ms, launches and amounts of a slot's spans recorded so far (and clears them); it waits for their
+ * events.  No reference counterpart. */
 int ndmps_profile_enable(int on);
 int ndmps_profile_collect(int slot, double* h_ms, int64_t* h_launches, int64_t* h_bytes);
 
@@ -235,6 +242,21 @@ int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t stride_G, 
                                 int64_t k_max, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
 int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const int64_t* h_k, int64_t k_max,
                                  void* d_ws, int64_t ws_bytes, int* h_status, ndmps_stream_t stream);
+/* The resident tridiagonalisation (orders 129..512, one launch for all columns of every matrix) makes the workgroups
+ * of a matrix wait for each other; every wait is bounded (3 s) and a team that gave up leaves status 2.
+ * _recover_f64: call after _values_f64 with the same batch / sizes / workspace where the host synchronises anyway:
+ * waits for `stream`; if any matrix carries status 2, phase 1 is done again for the batch on the per-column launches
+ * (asynchronous), *h_recovered (may be NULL) = 1.  _set_team(0 / 1): resident launch off / on for the calling host
+ * thread, returns the previous setting.  _team_fallbacks: how often a resident launch was given up and redone
+ * (process-wide); _note_team_fallback: for callers that repeat a sequence of their own.
+ * ndmps_debug_inject_team_abort(n): TEST HOOK -- the next n resident launches are replaced by what an aborted one
+ * leaves behind (status 2, reduction not done), without the 3 s wait. */
+int ndmps_syevd_topk_recover_f64(int batch, const int64_t* h_n, int64_t k_max, void* d_ws, int64_t ws_bytes,
+                                 int* h_recovered, ndmps_stream_t stream);
+int ndmps_syevd_topk_set_team(int enabled);
+int64_t ndmps_syevd_topk_team_fallbacks(void);
+int ndmps_syevd_topk_note_team_fallback(void);
+int ndmps_debug_inject_team_abort(int launches);
 /* Phase 2 with the rank decided ON THE DEVICE from phase 1's eigenvalues: k_b = #{i < k_cap : sqrt(w_i) > cutoff
  * sqrt(w_0)}, at least 1.  Columns k_b .. k_cap-1 of V are zero-filled, so a caller sizes everything by k_cap and
  * never waits for the rank.  d_ranks[b] (device) receives k_b, d_spectra (may be NULL) the k_cap leading singular

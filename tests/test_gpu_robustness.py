@@ -1,0 +1,147 @@
+"""GPU tests of the ways out of the latency-bound kernels (no reference counterpart: the reference is single
+threaded NumPy): the resident tridiagonalisation that gives up (status 2) and is redone on the per-column launches,
+and turn-taking between streams that share a hardware queue.
+
+The abort itself (a team waiting 3 s for a workgroup that never comes) is not provoked on the GPU: the host-side
+hook ``ndmps_debug_inject_team_abort`` replaces the next resident launches by what an aborted one leaves behind
+(status 2 in every descriptor, reduction not done).
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+from imgcompressionmps_amd import NDMPS, _lib  # noqa: E402
+from imgcompressionmps_amd.core import batch as batch_mod  # noqa: E402
+from oracle.metrics import synthetic_mri  # noqa: E402
+from oracle.ndmps_oracle import OracleNDMPS  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device; the product has no CPU path")
+    _lib.load()
+
+
+@pytest.fixture()
+def lib():
+    lib = _lib.load()
+    yield lib
+    lib.ndmps_debug_inject_team_abort(0)
+    lib.ndmps_syevd_topk_set_team(1)
+
+
+def _spd(n, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((2 * n, n))
+    return a.T @ a
+
+
+def test_solver_recovers_from_an_aborted_resident_launch(lib):
+    """values -> recover -> vectors: with status 2 injected, recover redoes phase 1 on the column launches, says so,
+    and the eigenpairs are LAPACK's."""
+    n, k, batch = 256, 32, 3
+    g = np.stack([_spd(n, 10 + b) for b in range(batch)])
+    dg = torch.from_numpy(g).to(DEV)
+    v = torch.empty_like(dg)
+    w = torch.empty((batch, n), dtype=torch.float64, device=DEV)
+    nbytes = int(lib.ndmps_syevd_topk_workspace_bytes(n, batch, k))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    sizes = _lib.i64_array([n] * batch)
+    before = int(lib.ndmps_syevd_topk_team_fallbacks())
+    for inject, expect in ((1, 1), (0, 0)):
+        lib.ndmps_debug_inject_team_abort(inject)
+        _lib.check(lib.ndmps_syevd_topk_values_f64(batch, dg.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(), n,
+                                                   k, ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        rec = C.c_int(-1)
+        _lib.check(lib.ndmps_syevd_topk_recover_f64(batch, sizes, k, ws.data_ptr(), nbytes, C.byref(rec), _lib.stream_ptr()))
+        assert rec.value == expect
+        status = (C.c_int * batch)()
+        _lib.check(lib.ndmps_syevd_topk_vectors_f64(batch, sizes, _lib.i64_array([k] * batch), k, ws.data_ptr(), nbytes,
+                                                    status, _lib.stream_ptr()))
+        assert list(status) == [0] * batch
+        wv, vv = w.cpu().numpy(), v.cpu().numpy()
+        for b in range(batch):
+            ref = np.linalg.eigvalsh(g[b])[::-1]
+            assert np.allclose(wv[b, :k], ref[:k], rtol=0, atol=1e-12 * ref[0])
+            vk = vv[b][:, :k]
+            assert np.abs(vk.T @ vk - np.eye(k)).max() < 1e-12
+            assert np.abs(g[b] @ vk - vk * wv[b, :k]).max() < 1e-11 * ref[0]
+    assert int(lib.ndmps_syevd_topk_team_fallbacks()) == before + 1
+
+
+def test_an_unrecovered_abort_is_reported_not_hidden(lib):
+    """Without the recover call the status stays 2 through phase 2 (a later Cholesky breakdown does not mask it)."""
+    n, k = 256, 16
+    dg = torch.from_numpy(_spd(n, 3)).to(DEV)
+    v = torch.empty_like(dg)
+    w = torch.empty(n, dtype=torch.float64, device=DEV)
+    nbytes = int(lib.ndmps_syevd_topk_workspace_bytes(n, 1, k))
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    sizes = _lib.i64_array([n])
+    lib.ndmps_debug_inject_team_abort(1)
+    _lib.check(lib.ndmps_syevd_topk_values_f64(1, dg.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(), n, k,
+                                               ws.data_ptr(), nbytes, _lib.stream_ptr()))
+    status = (C.c_int * 1)()
+    _lib.check(lib.ndmps_syevd_topk_vectors_f64(1, sizes, _lib.i64_array([k]), k, ws.data_ptr(), nbytes, status,
+                                                _lib.stream_ptr()))
+    assert status[0] == 2
+
+
+@pytest.mark.parametrize("dtype", [None, torch.float64], ids=["fused_f32", "f64_storage"])
+def test_sweep_redoes_itself_on_the_column_launches(lib, dtype):
+    """The bond-capped sweep decides ranks on the device and learns of an abort only at its end: the fused fp32 sweep
+    (input intact) repeats itself inside the library, the others through NDMPS.from_tensors.  Either way the caller
+    gets the result of the column launches and the event is counted."""
+    xs = [synthetic_mri((64, 64, 64), seed=2025 + j) for j in range(2)]
+    chi = 32  # eigenproblems of order 256 at the middle sites: the resident launch is on their path
+    clean = NDMPS.from_tensors(xs, max_bond=chi, device=DEV, dtype=dtype)
+    before = int(lib.ndmps_syevd_topk_team_fallbacks())
+    lib.ndmps_debug_inject_team_abort(1)
+    again = NDMPS.from_tensors(xs, max_bond=chi, device=DEV, dtype=dtype)
+    assert int(lib.ndmps_syevd_topk_team_fallbacks()) == before + 1
+    assert lib.ndmps_syevd_topk_set_team(1) == 1  # the switch was put back
+    for a, b, x in zip(clean, again, xs):
+        assert a.bond_sizes() == b.bond_sizes()
+        ra, rb = a.to_tensor(), b.to_tensor()
+        assert np.linalg.norm(ra - rb) <= 2e-6 * np.linalg.norm(ra)
+        ref = OracleNDMPS.from_tensor(x, max_bond=chi)
+        assert b.bond_sizes() == ref.bond_sizes()
+        assert np.linalg.norm(rb - ref.to_tensor()) <= 2e-5 * np.linalg.norm(ref.to_tensor())
+
+
+def test_more_groups_than_hardware_queues_take_turns_without_stalling(lib):
+    """Streams beyond the runtime's hardware queues (4 by default) share one: a turn-taking spinner that landed between
+    another stream's acquire and release in a shared queue would wait for a release queued behind itself until the
+    3 s bound.  Turns are submitted atomically (util.hip), so no step may take anything like that long."""
+    raw = (C.c_void_p * 8)()
+    found = C.c_int(0)
+    _lib.check(lib.ndmps_streams_create(8, raw, C.byref(found)))
+    _lib.check(lib.ndmps_streams_destroy(8, raw))
+    groups = 8
+    assert found.value < groups, "every stream got a queue of its own: nothing is shared in this test"
+    # 128^3 at chi = 32: order-256 eigenproblems (resident launch + its turn) and, with 4 volumes per group, Gram
+    # launches big enough to take the Gram turn
+    xs = [torch.from_numpy(synthetic_mri((128, 128, 128), seed=2025 + j)).to(DEV) for j in range(4)]
+    xs = xs * groups
+    batch_mod.encode_decode_concurrent(xs, groups=groups, max_bond=32)  # warm-up: streams, plans, allocator
+    torch.cuda.synchronize()
+    worst = 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        objs, recs = batch_mod.encode_decode_concurrent(xs, groups=groups, max_bond=32)
+        torch.cuda.synchronize()
+        worst = max(worst, time.perf_counter() - t0)
+    assert worst < 1.0, f"a step of 32 volumes of 128^3 took {worst:.2f} s: a turn waited for its time-out"
+    ref = recs[0]
+    for j in range(0, len(recs), 4):  # every group encoded the same four volumes
+        assert float((recs[j] - ref).norm() / ref.norm()) < 1e-6
+    assert objs[0].bond_sizes() == [8, 32, 32, 32, 32, 8]

@@ -120,6 +120,24 @@ def test_container_header_is_validated_on_the_host():
     del bad["bonds"]
     with pytest.raises(ValueError):
         codec.loads(_container(bad))
+    # the fields that are only read after the payload: a missing or mistyped one is a ValueError too, never a
+    # KeyError / TypeError from half-way through the load
+    for key in ("mode", "norm", "dim"):
+        bad = dict(good)
+        del bad[key]
+        with pytest.raises(ValueError):
+            codec.loads(_container(bad))
+    for patch in ({"mode": 7}, {"norm": "yes"}, {"dim": 2}, {"dim": True}, {"norm_value": "1.0"}):
+        with pytest.raises(ValueError):
+            codec.loads(_container({**good, **patch}))
+    quantised = {**good, "dtype": "uint16"}
+    for patch in ({"bounds": None}, {"bounds": [[0, 1]] * 2}, {"bounds": [[0, 1], [0], [0, 1]]}, {"bounds": [[0, "a"]] * 3}):
+        with pytest.raises(ValueError):
+            codec.loads(_container({**quantised, **patch}))
+    bad = dict(quantised)
+    del bad["bounds"]
+    with pytest.raises(ValueError):
+        codec.loads(_container(bad))
 
 
 def test_gzip_members_are_inflated_with_a_length_cap():
