@@ -24,6 +24,15 @@ def main():
             back = scale_back(q, x.min(), x.max(), dt)
             out[f"{name}/{np.dtype(dt).name}/q"] = q
             out[f"{name}/{np.dtype(dt).name}/back"] = back
+        # fp32-representable values, as the GPU path stores its cores, through the reference's OWN flow: NDMPS holds
+        # float64 arrays (core/ndmps.py:56), so the values are widened first and the arithmetic is float64
+        x32 = x.astype(np.float32)
+        out[name + "/x32"] = x32
+        wide = x32.astype(np.float64)
+        for dt in (np.uint8, np.uint16):
+            q = scale_to_dtype(wide, dt)
+            out[f"{name}/x32/{np.dtype(dt).name}/q"] = q
+            out[f"{name}/x32/{np.dtype(dt).name}/back"] = scale_back(q, wide.min(), wide.max(), dt)
     out["bits"] = np.array([get_num_bits(d) for d in (np.uint8, np.uint16, np.int32, np.float32, np.float64)])
     np.savez_compressed(os.path.join(HERE, "filetools.npz"), **out)
     print("wrote filetools.npz")

@@ -319,7 +319,7 @@ def test_reductions_and_scale():
     assert np.array_equal(t.cpu().numpy(), x * np.float32(0.25))
 
 
-def test_quantise_bit_exact_against_reference_semantics():
+def test_quantise_bit_exact_against_reference_semantics():  # larger random input vs the oracle; fixture: next test
     x = np.random.default_rng(2).standard_normal((9, 7, 5)).astype(np.float32)
     t = dev(x)
     for dt in (np.uint8, np.uint16):
@@ -331,6 +331,30 @@ def test_quantise_bit_exact_against_reference_semantics():
         assert np.abs(back - refb).max() <= 1e-6 * np.abs(refb).max()
     with pytest.raises(ValueError):
         hft.scale_to_dtype(t, np.int32)
+
+
+def test_quantiser_against_the_reference_generated_fixture(golden_dir):
+    """The HIP quantiser / dequantiser on the INPUTS of tests/golden/filetools.npz against the outputs the reference's
+    own utils/filetools.py:20-39 produced for them (tests/golden/make_golden_filetools.py): fp64 kernels on the fp64
+    inputs and fp32 kernels on the fp32-representable inputs, quantised values bit for bit; scale_back bit for bit in
+    fp64, and the fp32 kernel's result = the fp32 rounding of the reference's float64 result."""
+    g = np.load(os.path.join(golden_dir, "filetools.npz"))
+    for name in ("a", "b", "c"):
+        for key, tdtype in ((name + "/x", torch.float64), (name + "/x32", torch.float32)):
+            x = g[key]
+            t = dev(x)
+            assert t.dtype == tdtype
+            prefix = name if key.endswith("/x") else name + "/x32"
+            for dt in (np.uint8, np.uint16):
+                n = np.dtype(dt).name
+                dq = hft.scale_to_dtype(t, dt)
+                q = hft.to_numpy_uint(dq, dt)
+                assert q.dtype == dt and np.array_equal(q, g[f"{prefix}/{n}/q"]), (key, n)
+                want = g[f"{prefix}/{n}/back"]
+                back64 = hft.scale_back(dq, float(x.min()), float(x.max()), dt, out_dtype=torch.float64).cpu().numpy()
+                assert np.array_equal(back64, want), (key, n)
+                back32 = hft.scale_back(dq, float(x.min()), float(x.max()), dt).cpu().numpy()
+                assert back32.dtype == np.float32 and np.array_equal(back32, want.astype(np.float32)), (key, n)
 
 
 # ------------------------------------------------------------------------------------ DCT

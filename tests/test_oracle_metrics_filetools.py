@@ -29,6 +29,13 @@ def test_filetools_against_reference(golden_dir):
             q = ft.scale_to_dtype(x, dt)
             assert q.dtype == dt and np.array_equal(q, g[f"{name}/{n}/q"])
             assert np.array_equal(ft.scale_back(q, x.min(), x.max(), dt), g[f"{name}/{n}/back"])
+        # fp32-representable input widened to float64 (the values the GPU path's cores hold)
+        wide = g[name + "/x32"].astype(np.float64)
+        for dt in (np.uint8, np.uint16):
+            n = np.dtype(dt).name
+            q = ft.scale_to_dtype(wide, dt)
+            assert np.array_equal(q, g[f"{name}/x32/{n}/q"])
+            assert np.array_equal(ft.scale_back(q, wide.min(), wide.max(), dt), g[f"{name}/x32/{n}/back"])
     assert [ft.get_num_bits(d) for d in (np.uint8, np.uint16, np.int32, np.float32, np.float64)] == g["bits"].tolist()
     with pytest.raises(ValueError):
         ft.get_num_bits(np.bool_)
