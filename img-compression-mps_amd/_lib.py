@@ -29,10 +29,12 @@ SIGNATURES = {
     "ndmps_profile_enable": (C.c_int, [C.c_int]),
     "ndmps_profile_collect": (C.c_int, [C.c_int, p_f64, p_i64, p_i64]),
     "ndmps_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, p_i64, C.c_int, p_i64]),
+    "ndmps_plan_create_reversed": (C.c_int, [C.POINTER(vp), C.c_int, p_i64, C.c_int, p_i64]),
     "ndmps_plan_destroy": (C.c_int, [vp]),
     "ndmps_plan_numel": (i64, [vp]),
     "ndmps_plan_is_tiled": (C.c_int, [vp]),
     "ndmps_plan_emulate": (C.c_int, [C.c_int, p_i64, C.c_int, p_i64, C.c_int, p_i64]),
+    "ndmps_plan_emulate_reversed": (C.c_int, [C.c_int, p_i64, C.c_int, p_i64, C.c_int, p_i64]),
     "ndmps_encode_permute": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "ndmps_decode_permute": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "ndmps_encode_permute_generic": (C.c_int, [vp, vp, vp, C.c_int, vp]),

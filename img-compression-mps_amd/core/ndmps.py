@@ -91,14 +91,17 @@ def _torch():
 class _Plan:
     """Permutation plan (device offset tables) for one tensor shape."""
 
-    def __init__(self, shape):
+    def __init__(self, shape, reverse_sites=False):
         lib = _lib.load()
         self.shape = tuple(int(s) for s in shape)
         self.factor_arr, _ = _core.get_factorlist(self.shape)
         self.qubit_size = np.prod(self.factor_arr, axis=1)
         handle = C.c_void_p()
         fa = np.ascontiguousarray(self.factor_arr, dtype=np.int64)
-        _lib.check(lib.ndmps_plan_create(
+        # reverse_sites: destination = the site-order tensor with its axes reversed (the mirrored chain a
+        # left-to-right sweep is run on); qubit_size stays in the reference's order
+        create = lib.ndmps_plan_create_reversed if reverse_sites else lib.ndmps_plan_create
+        _lib.check(create(
             C.byref(handle), len(self.shape), _lib.i64_array(self.shape), fa.shape[0],
             fa.ctypes.data_as(_lib.p_i64)))
         self.handle = handle
@@ -150,11 +153,11 @@ class _Plan:
 _CACHE_LOCK = threading.Lock()  # concurrent groups (core/batch.py) reach the caches from several host threads
 
 
-def _plan_for(shape, device_index):
-    key = (tuple(int(s) for s in shape), device_index)
+def _plan_for(shape, device_index, reverse_sites=False):
+    key = (tuple(int(s) for s in shape), device_index) + (("reversed",) if reverse_sites else ())
     with _CACHE_LOCK:
         if key not in _PLAN_CACHE:
-            _PLAN_CACHE[key] = _Plan(shape)  # plan tables are uploaded with synchronous copies
+            _PLAN_CACHE[key] = _Plan(shape, reverse_sites)  # plan tables are uploaded with synchronous copies
         return _PLAN_CACHE[key]
 
 
@@ -313,7 +316,7 @@ class NDMPS:
     # ---------------------------------------------------------------------- encode
     @classmethod
     def from_tensor(cls, tensor, norm: bool = False, mode: str = "Std", max_bond=None,
-                    cutoff: float = 1e-10, device=None, dtype=None) -> "NDMPS":
+                    cutoff: float = 1e-10, device=None, dtype=None, sweep_from: str = "right") -> "NDMPS":
         """
         Create an NDMPS instance from a tensor with encoding and optional normalization.
 
@@ -324,13 +327,16 @@ class NDMPS:
         cutoff : relative singular-value cutoff of the sweep (quimb from_dense default).
         dtype : storage type in HBM, ``torch.float32`` (default), ``torch.bfloat16`` or ``torch.float64``
             (the reference's own element type; see from_tensors).
+        sweep_from : "right" (default) or "left": which end quimb's ``from_dense`` (ndmps.py:74) starts from; see
+            from_tensors.
         """
         return cls.from_tensors([tensor], norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff,
-                                device=device, dtype=dtype)[0]
+                                device=device, dtype=dtype, sweep_from=sweep_from)[0]
 
     @classmethod
     def from_tensors(cls, tensors, norm: bool = False, mode: str = "Std", max_bond=None,
-                     cutoff: float = 1e-10, device=None, dtype=None, reconstruct: bool = False):
+                     cutoff: float = 1e-10, device=None, dtype=None, reconstruct: bool = False,
+                     sweep_from: str = "right"):
         """
         Encode a list of independent tensors OF THE SAME SHAPE in one batched pass (what the
         reference does with a Python loop, evaluation/benchmark.py:73-76).  The volumes go through
@@ -352,6 +358,15 @@ class NDMPS:
         fp32 storage.  The sweep's relative cutoff is clamped below at 1e-8 (singular values come from fp64 Gram
         matrices).
 
+        ``sweep_from`` names the convention of quimb's ``MatrixProductState.from_dense`` (ndmps.py:74), whose source is
+        not available here: "right" (the default, what SURVEY states for quimb 1.9.0) sweeps site L-1 .. 1,
+        keeps V^T as the site and carries U S to the left, so sites 1..L-1 are right-isometric and site 0 holds the norm;
+        "left" is the other possible convention -- site 0 .. L-2, U is the site, S V^T is carried to the right, the
+        norm ends up on the last site.  It is computed as the same sweep on the mirrored chain (the reshape stage writes
+        the site-order tensor with its axes reversed, the cores come back transposed and in reverse order).  The two
+        give the same exact MPS up to gauge, DIFFERENT truncations (each cuts the bonds in its own order), different
+        ``boundary_list`` and a different starting point for ``compress``.
+
         ``reconstruct=True`` returns ``(objects, reconstructions)``: the chain products of the whole list are issued
         as soon as the sweep has returned, BEFORE the Python objects are built (their construction then runs
         under the decode instead of in front of it); the reconstructions (device tensors) equal
@@ -362,7 +377,9 @@ class NDMPS:
         tensors = list(tensors)
         if not tensors:
             return ([], []) if reconstruct else []
-        args = (tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct)
+        if sweep_from not in ("right", "left"):
+            raise ValueError("sweep_from must be 'right' or 'left'")
+        args = (tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct, sweep_from == "left")
         try:
             return cls._encode_group(*args)
         except _lib.NdmpsTeamAbort:
@@ -377,7 +394,7 @@ class NDMPS:
                 lib.ndmps_syevd_topk_set_team(was)
 
     @classmethod
-    def _encode_group(cls, tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct):
+    def _encode_group(cls, tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct, mirrored=False):
         """One lockstep group through norm / DCT / reshape stage / sweep (/ decode): the body of from_tensors."""
         torch = _torch()
         lib = _lib.load()
@@ -420,10 +437,15 @@ class NDMPS:
             raise ValueError("from_tensors needs tensors of one shape; encode other shapes separately")
         batch = len(xs)
         with torch.cuda.device(device):
-            plan = _plan_for(shape, device.index)
+            ref_plan = _plan_for(shape, device.index)  # the reference's site order (qubit_size, decode)
+            # mirrored (sweep_from="left"): the sweep runs on the chain read backwards -- the reshape stage writes the
+            # site-order tensor with its axes reversed and `dims` below are the sites in that order
+            plan = _plan_for(shape, device.index, reverse_sites=True) if mirrored else ref_plan
             stream = _lib.stream_ptr()
             numel = plan.numel
-            dims = [int(q) for q in plan.qubit_size]
+            dims = [int(q) for q in ref_plan.qubit_size]
+            if mirrored:
+                dims = dims[::-1]
             L = len(dims)
             cdims = _lib.i64_array(dims)
             mb = int(max_bond) if max_bond else 0
@@ -497,7 +519,8 @@ class NDMPS:
             offs = [int(core_off[i]) for i in range(L + 1)]
             spec_offs = [int(spec_off[i]) for i in range(L + 1)]
             recs = None
-            n_tail = int(lib.ndmps_chain_tail_columns(L, cdims)) if (reconstruct and not bf16 and not f64 and batch > 1) else 0
+            n_tail = (int(lib.ndmps_chain_tail_columns(L, cdims))
+                      if (reconstruct and not bf16 and not f64 and batch > 1 and not mirrored) else 0)
             if n_tail > 0 and not os.environ.get("NDMPS_NO_FUSED_DECODE"):
                 # decode straight from the arena: padded cores are valid cores of the cap bonds (zeros beyond the rank)
                 dec_bonds = (C.c_int64 * (batch * (L + 1)))()
@@ -530,7 +553,7 @@ class NDMPS:
                     recs = done
                 del cws
             per_site = None
-            if padded and bool((bonds_np == caps).all()):
+            if padded and bool((bonds_np == caps).all()) and not mirrored:
                 # every cap binds: the padded cores ARE the cores; L narrow / view / unbind calls serve the whole
                 # group (per-core slicing was 2 ms of host time per group of 32 with the GPU idle)
                 per_site = [arena_all[:, offs[i]: offs[i] + int(caps[i]) * dims[i] * int(caps[i + 1])]
@@ -556,8 +579,18 @@ class NDMPS:
                             view = arena_all[b, offs[i]: offs[i] + k0 * dims[i] * k1].view(k0, dims[i], k1)
                             # truncated arenas are compact, keep the views; exact sweeps own worst-case arenas
                             cores.append(view if mb else view.clone())
+                counts = [min(lefts[i], dims[i] * int(kb[i + 1])) for i in range(L)]
+                spec_view = (spec_np[b], spec_offs, counts)
+                if mirrored:
+                    # back to the reference's chain: site j is mirrored site L-1-j with its bond axes swapped; the
+                    # values of mirrored bond (i-1 | i) belong to bond (L-i-1 | L-i)
+                    cores = [c.permute(2, 1, 0).contiguous() for c in reversed(cores)]
+                    row = spec_np[b]
+                    spec_view = None
+                    mirrored_spectra = [None] + [row[spec_offs[L - j]: spec_offs[L - j] + counts[L - j]].copy()
+                                                 for j in range(1, L)]
                 obj = cls.__new__(cls)  # the fields of __init__, without its array conversions (32 objects per group)
-                obj.qubit_size = plan.qubit_size.copy()
+                obj.qubit_size = ref_plan.qubit_size.copy()
                 obj._encoding_map = None
                 obj.mps = DeviceMPS(cores, _trusted=True)
                 obj.dim = len(shape)
@@ -567,7 +600,9 @@ class NDMPS:
                 obj.boundary_list = bl0
                 obj._shape = shape
                 # singular values of the sweep, cut out of the group's buffer on first use
-                obj._spectra_lazy = (spec_np[b], spec_offs, [min(lefts[i], dims[i] * int(kb[i + 1])) for i in range(L)])
+                obj._spectra_lazy = spec_view
+                if mirrored:
+                    obj.sweep_spectra = mirrored_spectra
                 objs.append(obj)
             with _span("state"):
                 # boundary_list (ndmps.py:75) and norm_value (ndmps.py:76) of every volume from one
@@ -590,7 +625,8 @@ class NDMPS:
                     mm_np = np.asarray(mm, dtype=np.float64).reshape(batch, L, 2)
                     for b, o in enumerate(objs):
                         o.boundary_list = mm_np[b]
-                        o.norm_value = np.sqrt(ss[b * L])
+                        # the site that carries the norm: 0 after a right-to-left sweep, L-1 after the mirrored one
+                        o.norm_value = np.sqrt(ss[b * L + (L - 1 if mirrored else 0)])
         if reconstruct:
             return objs, (recs if recs is not None else cls.to_tensors(objs, as_torch=True))
         return objs

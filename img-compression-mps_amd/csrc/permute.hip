@@ -220,7 +220,7 @@ int upload(ndmps_plan* plan, const std::vector<T>& host, const T** dev_out) {
   return NDMPS_OK;
 }
 
-int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L_in, const int64_t* f_in) {
+int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L_in, const int64_t* f_in, bool reverse_sites = false) {
   DevPlan& dp = plan->dev;
   dp.ndim = ndim;
   plan->L = L_in;
@@ -241,7 +241,7 @@ int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L_in, const
       --lo;
       size *= sd[lo];
     }
-    if (lo > 0 && size >= kTileMin / 2) {
+    if (!reverse_sites && lo > 0 && size >= kTileMin / 2) {
       const int64_t f_last = fbuf[(lo - 1) * ndim + ndim - 1];
       int64_t S = 1;
       for (int64_t c = 2; c <= f_last; ++c)
@@ -281,6 +281,13 @@ int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L_in, const
   for (int l = 0; l < L; ++l)
     for (int j = 0; j < ndim; ++j) site_dim[l] *= f[l * ndim + j];
   for (int l = L - 2; l >= 0; --l) site_stride[l] = site_stride[l + 1] * site_dim[l + 1];
+  // reverse_sites: the destination is the site-order tensor with its axes reversed, C-order over (d_{L-1} .. d_0) --
+  // what a left-to-right sweep sees as "the sites to its right".  Site l keeps its digits and its source offsets;
+  // only its place in the destination changes (site 0 becomes the fastest axis).
+  if (reverse_sites) {
+    site_stride[0] = 1;
+    for (int l = 1; l < L; ++l) site_stride[l] = site_stride[l - 1] * site_dim[l - 1];
+  }
   // w[l][j]: weight of digit (l, j) inside coordinate x_j = product of later radices
   std::vector<int64_t> w((size_t)L * ndim, 1);
   for (int j = 0; j < ndim; ++j)
@@ -317,6 +324,10 @@ int build_plan(ndmps_plan* plan, int ndim, const int64_t* shape, int L_in, const
     }
   }
 
+  if (reverse_sites) {  // from here on "site l" is the l-th axis of the destination
+    std::reverse(site_dim.begin(), site_dim.end());
+    std::reverse(site_tab.begin(), site_tab.end());
+  }
   // group consecutive sites, lowest group first (it may be as large as one LDS tile)
   std::vector<std::pair<int, int>> groups;  // [first_site, last_site] inclusive, low -> high
   int hi = L - 1;
@@ -460,14 +471,14 @@ int dispatch(const ndmps_plan* plan, const void* in, void* out, int elem_bytes, 
 
 }  // namespace
 
-extern "C" int ndmps_plan_create(ndmps_plan_t** out, int ndim, const int64_t* h_shape, int L,
-                                 const int64_t* h_factor_arr) {
+namespace {
+int plan_create(ndmps_plan_t** out, int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr, bool reverse_sites) {
   NDMPS_REQUIRE(out != nullptr && h_shape != nullptr && h_factor_arr != nullptr, "NULL argument");
   NDMPS_REQUIRE(ndim >= 1 && ndim <= kMaxDim, "ndim=%d outside [1, %d]", ndim, kMaxDim);
   NDMPS_REQUIRE(L >= 1 && L <= kMaxSites, "L=%d outside [1, %d]", L, kMaxSites);
   ndmps_plan* plan = new ndmps_plan();
   memset(&plan->dev, 0, sizeof(DevPlan));
-  int rc = build_plan(plan, ndim, h_shape, L, h_factor_arr);
+  int rc = build_plan(plan, ndim, h_shape, L, h_factor_arr, reverse_sites);
   if (rc == NDMPS_OK) rc = upload_plan(plan);
   if (rc != NDMPS_OK) {
     ndmps_plan_destroy(plan);
@@ -475,6 +486,21 @@ extern "C" int ndmps_plan_create(ndmps_plan_t** out, int ndim, const int64_t* h_
   }
   *out = plan;
   return NDMPS_OK;
+}
+}  // namespace
+
+extern "C" int ndmps_plan_create(ndmps_plan_t** out, int ndim, const int64_t* h_shape, int L,
+                                 const int64_t* h_factor_arr) {
+  return plan_create(out, ndim, h_shape, L, h_factor_arr, false);
+}
+
+// The same permutation onto the site-order tensor with its AXES REVERSED, C-order over (d_{L-1}, .., d_0): the
+// tensor a left-to-right sweep works on when it is run as a right-to-left sweep of the mirrored chain
+// (NDMPS.from_tensor(sweep_from="left")).  Every entry point that takes a plan works on it unchanged; "site order"
+// then means the reversed order (ndmps_plan_split_offsets: n_cols = a product of LEADING site dimensions).
+extern "C" int ndmps_plan_create_reversed(ndmps_plan_t** out, int ndim, const int64_t* h_shape, int L,
+                                          const int64_t* h_factor_arr) {
+  return plan_create(out, ndim, h_shape, L, h_factor_arr, true);
 }
 
 extern "C" int ndmps_plan_destroy(ndmps_plan_t* plan) {
@@ -490,14 +516,27 @@ extern "C" int ndmps_plan_destroy(ndmps_plan_t* plan) {
 //   mode 1: generic decode  -> site-order offset read for every C-order source position
 //   mode 2: tiled encode    -> source offset stored at every site-order position
 //           (h_out[i] = -1 everywhere when the plan is not tiled)
+namespace {
+int plan_emulate(int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr, int mode, int64_t* h_out,
+                 bool reverse_sites);
+}
 extern "C" int ndmps_plan_emulate(int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr,
                                   int mode, int64_t* h_out) {
+  return plan_emulate(ndim, h_shape, L, h_factor_arr, mode, h_out, false);
+}
+extern "C" int ndmps_plan_emulate_reversed(int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr,
+                                           int mode, int64_t* h_out) {
+  return plan_emulate(ndim, h_shape, L, h_factor_arr, mode, h_out, true);
+}
+namespace {
+int plan_emulate(int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr, int mode, int64_t* h_out,
+                 bool reverse_sites) {
   NDMPS_REQUIRE(h_shape && h_factor_arr && h_out, "NULL argument");
   NDMPS_REQUIRE(ndim >= 1 && ndim <= kMaxDim, "ndim=%d outside [1, %d]", ndim, kMaxDim);
   NDMPS_REQUIRE(L >= 1 && L <= kMaxSites, "L=%d outside [1, %d]", L, kMaxSites);
   ndmps_plan plan;
   memset(&plan.dev, 0, sizeof(DevPlan));
-  NDMPS_TRY(build_plan(&plan, ndim, h_shape, L, h_factor_arr));
+  NDMPS_TRY(build_plan(&plan, ndim, h_shape, L, h_factor_arr, reverse_sites));
   const DevPlan& p = plan.dev;
   const HostTables& h = plan.host;
   if (mode == 0) {
@@ -537,6 +576,7 @@ extern "C" int ndmps_plan_emulate(int ndim, const int64_t* h_shape, int L, const
   }
   return plan.tiled;
 }
+}  // namespace
 
 // Source offsets of the site-order tensor viewed as a (numel / n_cols) x n_cols matrix: the offset of a
 // site-order element is additive over sites, so element (r, c) sits at h_row_off[r] + h_col_off[c] of the C-order

@@ -71,6 +71,12 @@ int ndmps_profile_collect(int slot, double* h_ms, int64_t* h_launches, int64_t* 
  * --------------------------------------------------------------------------------- */
 int ndmps_plan_create(ndmps_plan_t** out, int ndim, const int64_t* h_shape, int L,
                       const int64_t* h_factor_arr);
+/* The same permutation onto the site-order tensor with its AXES REVERSED (C-order over d_{L-1} .. d_0): what a
+ * left-to-right sweep (quimb's other from_dense convention, SURVEY a4's caveat) works on when it runs as a
+ * right-to-left sweep of the mirrored chain.  Every plan entry point works on it; "site order" then means the reversed
+ * order (ndmps_plan_split_offsets: n_cols = a product of LEADING site dimensions). */
+int ndmps_plan_create_reversed(ndmps_plan_t** out, int ndim, const int64_t* h_shape, int L,
+                               const int64_t* h_factor_arr);
 int ndmps_plan_destroy(ndmps_plan_t* plan);
 int64_t ndmps_plan_numel(const ndmps_plan_t* plan);
 /* 1 if the LDS-tiled kernels are used for this plan, 0 for the generic gather */
@@ -82,6 +88,8 @@ int ndmps_plan_is_tiled(const ndmps_plan_t* plan);
  * the plan is not tiled).  Returns 1/0 (tiled or not) or a negative error code. */
 int ndmps_plan_emulate(int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr,
                        int mode, int64_t* h_out);
+int ndmps_plan_emulate_reversed(int ndim, const int64_t* h_shape, int L, const int64_t* h_factor_arr,
+                                int mode, int64_t* h_out);
 /* dst (C-order over site dims d_0..d_{L-1}) <- src (C-order over shape); bit-exact */
 int ndmps_encode_permute(const ndmps_plan_t* plan, const void* d_src, void* d_dst,
                          int elem_bytes, ndmps_stream_t stream);

@@ -46,13 +46,33 @@ def _truncate(s, cutoff, max_bond, keep_at_least_one=True):
     return k
 
 
-def mps_from_dense(dense, dims, cutoff=1e-10, max_bond=None):
-    """Right->left SVD sweep; returns cores [(chi_i, d_i, chi_{i+1})] and spectra."""
+def mps_from_dense(dense, dims, cutoff=1e-10, max_bond=None, sweep_from="right"):
+    """SVD sweep; returns cores [(chi_i, d_i, chi_{i+1})] and spectra (spectra[i]: bond between sites i-1 and i).
+
+    ``sweep_from="right"`` (default): quimb 1.9.0's ``from_dense`` as SURVEY a4 states it -- sites L-1 .. 1, Vh is the
+    site, U S is carried left.  ``sweep_from="left"``: the other convention a from_dense could have (SURVEY a4's
+    caveat: quimb's source cannot be read here) -- sites 0 .. L-2, U is the site, S Vh is carried right.  Written out
+    on its own (not as a mirrored right sweep) so that it checks the GPU path's mirroring."""
     dims = [int(d) for d in dims]
     L = len(dims)
-    work = np.asarray(dense, dtype=np.float64).reshape(-1, 1)  # (rows, chi_right)
     cores = [None] * L
     spectra = [None] * L
+    if sweep_from == "left":
+        work = np.asarray(dense, dtype=np.float64).reshape(1, -1)  # (chi_left, everything to the right)
+        chi_l = 1
+        for i in range(L - 1):
+            cols = work.size // (chi_l * dims[i])
+            u, s, vh = np.linalg.svd(work.reshape(chi_l * dims[i], cols), full_matrices=False)
+            k = _truncate(s, cutoff, max_bond)
+            cores[i] = u[:, :k].reshape(chi_l, dims[i], k)
+            spectra[i + 1] = s.copy()
+            work = s[:k, None] * vh[:k]
+            chi_l = k
+        cores[L - 1] = work.reshape(chi_l, dims[L - 1], 1)
+        return cores, spectra
+    if sweep_from != "right":
+        raise ValueError("sweep_from must be 'right' or 'left'")
+    work = np.asarray(dense, dtype=np.float64).reshape(-1, 1)  # (rows, chi_right)
     chi_r = 1
     for i in range(L - 1, 0, -1):
         rows = work.size // (dims[i] * chi_r)

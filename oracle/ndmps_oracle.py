@@ -51,7 +51,7 @@ class OracleNDMPS:
     # ------------------------------------------------------------------ encode
     @classmethod
     def from_tensor(cls, tensor, norm=False, mode="Std", max_bond=None, cutoff=1e-10,
-                    materialise_map=True):
+                    materialise_map=True, sweep_from="right"):
         tensor = np.asarray(tensor).astype(np.float64)
         shape = tuple(int(s) for s in tensor.shape)
         if materialise_map:
@@ -75,7 +75,7 @@ class OracleNDMPS:
             flat_dest = _im.flat_destination(shape).reshape(-1)
             dense.reshape(-1)[flat_dest] = tensor.reshape(-1)
 
-        cores, spectra = mps_from_dense(dense, qubit_size, cutoff=cutoff, max_bond=max_bond)
+        cores, spectra = mps_from_dense(dense, qubit_size, cutoff=cutoff, max_bond=max_bond, sweep_from=sweep_from)
         mps = OracleMPS(cores)
         boundary = [[np.min(a), np.max(a)] for a in mps.arrays]
         norm_value = np.sqrt(mps @ mps)

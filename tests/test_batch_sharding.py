@@ -150,3 +150,81 @@ def test_bench_default_job_is_baselines_batch_of_64_distinct_seeds():
     job8 = bench.job_descriptor(bench.parse(["--gpus", "8", "--batch", "8"]), 8)
     owned = [bench.volume_seeds(job8, r) for r in range(8)]
     assert sum(owned, []) == list(range(2025, 2089)) and all(len(o) == 8 for o in owned)
+
+
+# ------------------------------------------------------------- strong scaling (BASELINE config 4) and the config table
+def test_bench_configs_name_baselines_workloads():
+    import bench
+
+    j = bench.job_descriptor(bench.parse(["--config", "2"]), 1)
+    assert (j["size"], j["chi"], j["mode"], j["n_volumes"], j["scaling"]) == (256, 32, "Std", 64, "weak")
+    j = bench.job_descriptor(bench.parse(["--config", "3"]), 1)
+    assert (j["size"], j["chi"], j["mode"], j["n_volumes"], j["scaling"]) == (512, 64, "DCT", 8, "weak")
+    j = bench.job_descriptor(bench.parse(["--config", "5"]), 1)
+    assert (j["kind"], j["shape"], j["chi"], j["n_volumes"], j["scaling"]) == ("tensor", [128, 128, 64, 256], 128, 1, "strong")
+    # config 4: 64 volumes of 128^3 IN TOTAL, whatever the number of GPUs; 8 per GPU on the 8-GPU node
+    for world, per in ((1, 64), (2, 32), (4, 16), (8, 8)):
+        j = bench.job_descriptor(bench.parse(["--config", "4", "--gpus", str(world)]), world)
+        assert (j["size"], j["chi"], j["n_volumes"], j["batch_per_gpu"], j["scaling"]) == (128, 32, 64, per, "strong")
+        owned = [bench.volume_seeds(j, r) for r in range(world)]
+        assert sum(owned, []) == list(range(2025, 2089)) and all(len(o) == per for o in owned)
+        assert bench.throughput(j, 128 ** 3, 10, 2.0) == pytest.approx(64 * 128 ** 3 * 10 / 2.0 / 1e6)
+    # --total-volumes turns the headline workload into the same kind of run; an explicit --batch keeps weak scaling
+    j = bench.job_descriptor(bench.parse(["--total-volumes", "64", "--gpus", "8"]), 8)
+    assert (j["size"], j["chi"], j["n_volumes"], j["batch_per_gpu"], j["scaling"]) == (256, 64, 64, 8, "strong")
+    j = bench.job_descriptor(bench.parse(["--config", "4", "--batch", "16", "--gpus", "2"]), 2)
+    assert (j["n_volumes"], j["batch_per_gpu"], j["scaling"]) == (32, 16, "weak")
+    # uneven shards: every volume still owned exactly once
+    j = bench.job_descriptor(bench.parse(["--total-volumes", "10", "--gpus", "4"]), 4)
+    assert sorted(sum((bench.volume_seeds(j, r) for r in range(4)), [])) == list(range(2025, 2035))
+
+
+def _strong_worker(rank, world, port, q):
+    """The strong-scaling mode around a stub step at world size 2 under gloo: the broadcast descriptor fixes the TOTAL,
+    every rank owns total / world volumes, the throughput counts the total once."""
+    import time
+
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        args = bench.parse(["--config", "4", "--gpus", str(world), "--steps", "2", "--warmup", "1"])
+        if rank != 0:
+            args.total_volumes = 7  # overwritten by rank 0's descriptor
+        job = batch.broadcast_job(bench.job_descriptor(args, world) if rank == 0 else None, src=0)
+        seeds = bench.volume_seeds(job, rank)
+
+        def step():
+            time.sleep(0.001 * len(seeds) * (rank + 1))  # work proportional to the shard; rank 1 is the slow one
+
+        def reduce_max(v):
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        elapsed = bench.timed_steps(step, args.steps, args.warmup, dist.barrier, reduce_max)
+        q.put((rank, job, seeds, elapsed, bench.throughput(job, 128 ** 3, args.steps, elapsed)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_strong_scaling_mode_world_size_2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, job0, seeds0, el0, v0), (_, job1, seeds1, el1, v1) = results
+    assert job0 == job1 and job0["scaling"] == "strong" and job0["n_volumes"] == 64 and job0["batch_per_gpu"] == 32
+    assert seeds0 == list(range(2025, 2057)) and seeds1 == list(range(2057, 2089))
+    assert el0 == el1 and el0 >= 2 * 0.064
+    assert v0 == v1 == pytest.approx(64 * 128 ** 3 * 2 / el0 / 1e6)  # the total counted once, not per rank

@@ -1175,10 +1175,14 @@ def test_gram_bf16_is_exact_in_fp64():
 
 
 @pytest.mark.parametrize("shape,chi,mode", [((32, 32, 16, 24), 20, "Std"), ((64, 64, 64), 32, "Std"),
-                                            ((32, 32, 16, 24), 16, "DCT"), ((48, 40, 36), 12, "Std")], ids=str)
+                                            ((32, 32, 16, 24), 16, "DCT"), ((48, 40, 36), 12, "Std"),
+                                            ((64, 64, 32, 64), 128, "Std")], ids=str)
 def test_bf16_storage_matches_oracle_on_bf16_rounded_input(shape, chi, mode):
     """dtype=torch.bfloat16: bf16 volume, bf16 carried matrices and cores, bf16 chain; against the fp64 oracle on
-    the same bf16-rounded values.  Bonds are equal (the cap binds), everything else within BF16_TOL."""
+    the same bf16-rounded values.  Bonds are equal (the cap binds), everything else within BF16_TOL.
+    (64, 64, 32, 64) at chi = 128 is BASELINE config 5 at an eighth of its extent per axis pair: site dims
+    [64, 16, 16, 16, 32], exact bonds [64, 1024, 512, 32], so chi = 128 BINDS on two bonds and the order-2048
+    eigenproblem of config 5's middle sites (k = 128 of n = 16 x 128) is on the path."""
     xb = torch.from_numpy(synthetic_mri(shape, seed=5)).to(DEV).to(torch.bfloat16)
     obj = NDMPS.from_tensor(xb, max_bond=chi, mode=mode, dtype=torch.bfloat16)
     ref = OracleNDMPS.from_tensor(xb.float().cpu().numpy(), max_bond=chi, mode=mode)
@@ -1198,6 +1202,59 @@ def test_bf16_storage_matches_oracle_on_bf16_rounded_input(shape, chi, mode):
     obj.compress(0.05)
     assert all(c.dtype == torch.bfloat16 for c in obj.mps.cores)
     assert obj.to_tensor().shape == shape
+
+
+@pytest.mark.parametrize("shape,chi,mode,dtype,tol", [
+    ((32, 32), 8, "Std", None, 2e-5), ((64, 64, 64), 16, "Std", None, 2e-5), ((48, 40, 36), 12, "DCT", None, 3e-5),
+    ((16, 16, 8, 12), 10, "Std", None, 2e-5), ((128, 128, 128), 32, "Std", None, 2e-5),
+    ((64, 64, 64), 16, "Std", torch.float64, 1e-9), ((48, 40, 36), 12, "Std", torch.float64, 1e-9)], ids=str)
+def test_sweep_from_left_matches_the_oracles_left_sweep(shape, chi, mode, dtype, tol):
+    """quimb's OTHER possible from_dense convention (SURVEY a4's caveat): sites 0 .. L-2, U is the site, S V^T carried
+    right.  The GPU path runs it as the ordinary sweep on the mirrored chain (reversed-axes reshape stage, cores
+    transposed back); the oracle writes the left sweep out directly.  Same bar as the default convention."""
+    x = synthetic_mri(shape, seed=11)
+    obj = NDMPS.from_tensor(x, max_bond=chi, mode=mode, dtype=dtype, sweep_from="left")
+    ref = OracleNDMPS.from_tensor(x, max_bond=chi, mode=mode, sweep_from="left")
+    assert obj.bond_sizes() == ref.bond_sizes()
+    assert [tuple(c.shape) for c in obj.mps.cores] == [tuple(c.shape) for c in ref.mps.cores]
+    rec, rr = obj.to_tensor(), ref.to_tensor()
+    assert np.linalg.norm(rec - rr) <= tol * np.linalg.norm(rr)
+    x64 = x.astype(np.float64)
+    assert abs(compute_ssim_by_dim(x64, rec.astype(np.float64)) - compute_ssim_by_dim(x64, rr)) <= 1e-5
+    # the gauge: sites 0 .. L-2 are left-isometric, the norm sits on the last site
+    rtol = 1e-5 if dtype is None else 1e-10
+    assert math.isclose(obj.norm_value, ref.norm_value, rel_tol=rtol)
+    last = obj.mps.cores[-1].double()
+    assert math.isclose(float(last.norm()), ref.norm_value, rel_tol=rtol)
+    for c in obj.mps.cores[:-1]:
+        m = c.double().reshape(-1, c.shape[2])
+        assert float((m.T @ m - torch.eye(c.shape[2], dtype=torch.float64, device=DEV)).abs().max()) <= (2e-5 if dtype is None else 1e-10)
+    assert np.allclose(np.asarray(obj.boundary_list), np.asarray(ref.boundary_list), atol=2e-4 if dtype is None else 1e-8)
+    for i in range(1, len(ref.sweep_spectra)):
+        k = len(obj.sweep_spectra[i])
+        assert np.allclose(obj.sweep_spectra[i], ref.sweep_spectra[i][:k], rtol=0, atol=1e-5 * ref.sweep_spectra[i][0])
+    # the two conventions are different truncations of the same tensor, and compress starts from a different gauge
+    other = NDMPS.from_tensor(x, max_bond=chi, mode=mode, dtype=dtype)
+    assert other.bond_sizes() == obj.bond_sizes()
+    assert np.linalg.norm(other.to_tensor() - rec) > 10 * tol * np.linalg.norm(rr) or chi >= min(shape)
+    obj.compress(0.02)
+    ref.compress(0.02)
+    assert obj.bond_sizes() == ref.bond_sizes()
+    assert np.linalg.norm(obj.to_tensor() - ref.to_tensor()) <= 2 * tol * np.linalg.norm(rr)
+
+
+def test_sweep_from_left_exact_round_trip_and_lists():
+    x = np.random.default_rng(2025).random((96, 80)).astype(np.float32)
+    obj = NDMPS.from_tensor(x, sweep_from="left")
+    assert np.allclose(obj.to_tensor(), x, atol=2e-5)
+    xs = [synthetic_mri((32, 32, 32), seed=s) for s in (1, 2, 3)]
+    objs, recs = NDMPS.from_tensors(xs, max_bond=8, sweep_from="left", reconstruct=True)
+    for o, r, v in zip(objs, recs, xs):
+        single = NDMPS.from_tensor(v, max_bond=8, sweep_from="left")
+        assert o.bond_sizes() == single.bond_sizes()
+        assert np.allclose(r.cpu().numpy(), single.to_tensor(), atol=2e-6)
+    with pytest.raises(ValueError):
+        NDMPS.from_tensor(x, sweep_from="middle")
 
 
 def test_config5_full_size_bf16_storage_chi128_properties():

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 from imgcompressionmps_amd import NDMPS, _lib  # noqa: E402
 from imgcompressionmps_amd.core import sharded  # noqa: E402
 from imgcompressionmps_amd.core.ndmps import _plan_for  # noqa: E402
+from oracle import mps as omps  # noqa: E402
 from oracle.metrics import synthetic_mri  # noqa: E402
 
 DEV = "cuda:0"
@@ -50,6 +51,12 @@ def _check_against_single_gpu(x, chi, rank, world, group=None):
     err = float((full - dense).norm() / dense.norm())
     err_ref = float((ref_dense - dense).norm() / dense.norm())
     assert abs(err - err_ref) <= 1e-5 * max(err_ref, 1e-3)
+    # and against the ORACLE's sweep of the same site-order tensor, not only against the single-GPU HIP sweep
+    cores, _ = omps.mps_from_dense(dense.double().cpu().numpy(), dims, max_bond=chi)
+    assert mps.bond_sizes() == [int(c.shape[2]) for c in cores[:-1]]
+    want64 = omps.mps_to_dense(cores).reshape(-1)
+    got64 = full.double().cpu().numpy().reshape(-1)
+    assert np.linalg.norm(got64 - want64) <= 2e-5 * np.linalg.norm(want64)
     return True
 
 
@@ -62,6 +69,23 @@ def _need_gpu():
 @pytest.mark.parametrize("shape,chi", [((64, 64, 64), 16), ((128, 128, 128), 32), ((32, 32, 16, 24), 12)])
 def test_sharded_sweep_world_size_1_equals_the_ordinary_sweep(shape, chi):
     assert _check_against_single_gpu(synthetic_mri(shape, seed=5), chi, 0, 1)
+
+
+@pytest.mark.parametrize("shape,chi,why", [
+    ((512, 680), 16, "dims [34, 20, 8, 8, 8]: the first unfolding is already too short to shard (break at i = L - 1)"),
+    ((8, 512, 680), 64, "dims [160, 128, 136]: sharded down to i = 0, the replicated rest is a single-site tensor"),
+], ids=["breaks_at_once", "runs_to_site_0"])
+def test_sharded_sweep_edge_exits(shape, chi, why):
+    """The two ends of the loop in from_dense_sharded: no sharded site at all, and every site but the first sharded
+    (the gathered head then has one site and no bond of its own)."""
+    x = np.random.default_rng(2025).random(shape).astype(np.float32)
+    dense, dims = _site_order(x)
+    mps = sharded.from_dense_sharded(dense.clone(), dims, max_bond=chi)
+    cores, _ = omps.mps_from_dense(dense.double().cpu().numpy(), dims, max_bond=chi)
+    assert mps.bond_sizes() == [int(c.shape[2]) for c in cores[:-1]], why
+    want = omps.mps_to_dense(cores).reshape(-1)
+    got = mps.to_dense().double().cpu().numpy().reshape(-1)
+    assert np.linalg.norm(got - want) <= 2e-5 * np.linalg.norm(want), why
 
 
 def test_sharded_sweep_rejects_bad_arguments():
