@@ -212,13 +212,12 @@ def collect_slots(lib):
 
 
 def roofline_of(slots, steps):
-    """The roofline object of the DOMINANT instrumented kernel = the slot with the most device time in the timed region
-    (HIP events on the launching streams around every launch, csrc/util.hip), plus one line per other slot."""
+    """The roofline object: the instrumented kernel with the most device time in the timed region (HIP events on the
+    launching streams around every launch, csrc/util.hip) among those a roofline bounds -- the MFMA-bound Gram launches
+    and the HBM-bound column launches.  The resident tridiagonalisation is LATENCY-bound (one exchange between the
+    workgroups of a matrix per column, no trailing-matrix traffic): its span is reported next to the roofline
+    (`tridiagonalisation`), with its share of device time, and named as the larger one where it is."""
     busy = {s: v for s, v in slots.items() if v[1] > 0}
-    if not busy:
-        return {"kernel": None, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
-                "traffic": None, "note": "no instrumented kernel ran in the timed region"}
-    dom = max(busy, key=lambda s: busy[s][0])
 
     def line(slot):
         ms, launches, amount = busy[slot]
@@ -233,14 +232,28 @@ def roofline_of(slots, steps):
                 ("flops_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"): per_amount,
                 "launch_us": per_us, "launches_per_step": launches / steps, "device_ms_per_step": ms / steps}
 
-    roof = line(dom)
+    bounded = {s: v for s, v in busy.items() if s != SLOT_TEAM}
+    if not bounded:
+        roof = {"kernel": None, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+                "note": "no MFMA- or HBM-bound instrumented kernel ran in the timed region"}
+        dom = None
+    else:
+        dom = max(bounded, key=lambda s: bounded[s][0])
+        roof = line(dom)
     roof["traffic"] = None
     roof["measured"] = "HIP events on the launching streams around every launch of this kernel in the timed region"
     if dom == SLOT_GRAM:
         roof["traffic"], roof["traffic_source"] = pmc_traffic("gram128_kernel")
+    if dom in (SLOT_GRAM, SLOT_GRAM_SMALL):
         roof["peak_source"] = ("AMD MI355X spec, FP64 matrix 78.6 TFLOP/s = 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz; "
                                "77.7 measured with tools/scratch/mfma_f64_rate.hip (MI355X_MICROARCH.md lists no f64 row)")
-    roof["other_instrumented_kernels"] = [line(s) for s in sorted(busy) if s != dom]
+    roof["other_instrumented_kernels"] = [line(s) for s in sorted(bounded) if s != dom]
+    if SLOT_TEAM in busy:
+        t = line(SLOT_TEAM)
+        t["bound"] = "latency of the per-column exchange (no roofline applies: 2 x 8 n^2 bytes per matrix over the launch)"
+        t["span_covers"] = "the launch and its wait for the device-side turn"
+        t["larger_than_the_roofline_kernel"] = bool(dom is None or busy[SLOT_TEAM][0] > busy[dom][0])
+        roof["tridiagonalisation"] = t
     return roof
 
 

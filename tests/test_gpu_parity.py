@@ -353,8 +353,9 @@ def test_quantiser_against_the_reference_generated_fixture(golden_dir):
                 want = g[f"{prefix}/{n}/back"]
                 back64 = hft.scale_back(dq, float(x.min()), float(x.max()), dt, out_dtype=torch.float64).cpu().numpy()
                 assert np.array_equal(back64, want), (key, n)
-                back32 = hft.scale_back(dq, float(x.min()), float(x.max()), dt).cpu().numpy()
-                assert back32.dtype == np.float32 and np.array_equal(back32, want.astype(np.float32)), (key, n)
+                if tdtype == torch.float32:  # the fp32 kernel takes fp32 bounds: exact for fp32-representable input only
+                    back32 = hft.scale_back(dq, float(x.min()), float(x.max()), dt).cpu().numpy()
+                    assert back32.dtype == np.float32 and np.array_equal(back32, want.astype(np.float32)), (key, n)
 
 
 # ------------------------------------------------------------------------------------ DCT
