@@ -80,6 +80,11 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   unsigned char* piv;  // [B][n_max][kp]
   double* Tw;          // [B][t_stride] WY factors of the reflector groups (back-transformation)
   int64_t t_stride;
+  double* yb;          // [B][2][kBandMax][lda] band reduction: Y = A V of a panel, by parity of the panel
+  double* xb;          // [B][2][kBandMax][lda] band reduction: the next panel's columns, by parity
+  double* band;        // [B][n_max][2 kBandMax] band matrix, [column][distance below the diagonal]
+  double* qlog;        // [B][q_stride] reflectors of the bulge chase, [sweep][step][BW]
+  int64_t q_stride;
   long long* stamps;   // [B][16] wall-clock (100 MHz) marks of the single-workgroup kernels' phases (tools/trd_probe.py)
   int n_max, lda, kp;
 };
@@ -1732,6 +1737,8 @@ __global__ void trd_clear_status_kernel(TrdDesc* __restrict__ desc, int batch, T
   }
 }
 
+#include "eig_band.inc"
+
 // Test hook (ndmps_debug_inject_team_abort): what an aborted team launch leaves behind, without the 3 s wait
 __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1741,7 +1748,7 @@ __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
 // ------------------------------------------------------------------------------------------ host side
 struct TrdLayout {
   int64_t n_max, lda, kp;
-  int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, total;
+  int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, total;
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -1774,6 +1781,13 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_stamps = take(batch * 16 * 8);
   l.t_stride = (n_max + 8) * 4;  // groups of WYB reflectors, WYB^2 doubles each, WYB <= 4
   l.off_tw = take(batch * l.t_stride * 8);
+  // two-stage reduction (orders <= 512, eig_band.inc): exchange vectors, the band, the log of the bulge chase
+  const bool band_ok = n_max <= 512;
+  l.off_yb = take(band_ok ? batch * 2 * kBandMax * l.lda * 8 : 0);
+  l.off_xb = take(band_ok ? batch * 2 * kBandMax * l.lda * 8 : 0);
+  l.off_band = take(band_ok ? batch * n_max * 2 * kBandMax * 8 : 0);
+  l.q_stride = band_ok ? n_max * (n_max + 2 * kBandMax) : 0;
+  l.off_qlog = take(batch * l.q_stride * 8);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -1799,6 +1813,11 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.stamps = (long long*)(base + l.off_stamps);
   w.Tw = (double*)(base + l.off_tw);
   w.t_stride = l.t_stride;
+  w.yb = (double*)(base + l.off_yb);
+  w.xb = (double*)(base + l.off_xb);
+  w.band = (double*)(base + l.off_band);
+  w.qlog = (double*)(base + l.off_qlog);
+  w.q_stride = l.q_stride;
   w.n_max = (int)l.n_max;
   w.lda = (int)l.lda;
   w.kp = (int)l.kp;
@@ -1808,6 +1827,13 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
 // inverse-iteration kernel: Cholesky factor [128][129], aliased by the scaled tridiagonal as (d, e) pairs
 constexpr int kInvitLdsMax = kMaxK * (kMaxK + 1) * 8;  // >= kMaxN * 16
 constexpr size_t kTailLds = ((size_t)kTail * kTailLd + 4 * kTail) * sizeof(double);  // matrix + RowVec[kTail]
+
+// the resident launch may be switched off per host thread (the fallback after an abort runs the column launches)
+thread_local int g_team_off = 0;
+std::atomic<long long> g_team_fallbacks{0};
+std::atomic<int> g_inject_abort{0};
+
+constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction when NDMPS_TRD_BAND is not set (0: off)
 
 // kernels that need more than 64 KB of dynamic LDS are opted in once per device
 int trd_opt_in() {
@@ -1829,8 +1855,21 @@ int trd_opt_in() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_ortho_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_back2_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 8));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_back2_kernel<4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 8));
   done[dev] = true;
   return NDMPS_OK;
+}
+
+// Semi-bandwidth of the two-stage reduction for a batch whose largest order is n_max, 0 = one-stage paths.  A pure
+// function of its arguments and the environment: phase 1 and phase 2 of a solve must agree on it.
+int band_width_for(int64_t n_max) {
+  if (n_max > 512 || n_max <= kTail || getenv("NDMPS_TRD_NO_TEAM") || g_team_off) return 0;
+  const char* e = getenv("NDMPS_TRD_BAND");
+  const int bw = e ? atoi(e) : kBandDefault;
+  return (bw == 2 || bw == 4) ? bw : 0;
 }
 
 // workgroups of trd_team_kernel the current device keeps resident at once (occupancy x compute units)
@@ -1861,11 +1900,6 @@ int team_launch(hipStream_t s, F&& launch) {
   launch();
   return turn.end();
 }
-
-// the resident launch may be switched off per host thread (the fallback after an abort runs the column launches)
-thread_local int g_team_off = 0;
-std::atomic<long long> g_team_fallbacks{0};
-std::atomic<int> g_inject_abort{0};
 
 int trd_check_sizes(int batch, const int64_t* h_n, int64_t& n_max) {
   NDMPS_REQUIRE(batch >= 1 && batch <= 4096, "batch=%d outside [1, 4096]", batch);
@@ -1903,7 +1937,41 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
   // orders <= 512: one resident launch for all columns (trd_team_kernel; 2.2 ms for 1 .. 16 matrices of order
   // 512, 2.5 ms for 32, against 2.4 / 3.8 / 5.7 ms of column launches); NDMPS_TRD_NO_TEAM=1 keeps the column
   // launches (A/B timing, tests of that path)
-  const bool team = n_max <= 512 && n_max > kTail && !getenv("NDMPS_TRD_NO_TEAM") && !g_team_off;
+  const int bw = band_width_for(n_max);
+  const bool team = !bw && n_max <= 512 && n_max > kTail && !getenv("NDMPS_TRD_NO_TEAM") && !g_team_off;
+  if (bw) {
+    // two-stage reduction (eig_band.inc): dense -> band with one exchange per panel, then the bulge chase
+    int slots = 0;
+    NDMPS_TRY(team_slots(slots));
+    const int team_size = (int)ndmps::ceil_div(n_max, 32);
+    const int per_launch = std::max(1, slots / team_size);
+    int inject = g_inject_abort.load();
+    while (inject > 0 && !g_inject_abort.compare_exchange_weak(inject, inject - 1)) {
+    }
+    void* span = ndmps::span_begin(s);
+    if (inject > 0) {
+      hipLaunchKernelGGL(trd_inject_abort_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch);
+    } else {
+      NDMPS_TRY(team_launch(s, [&]() {
+        for (int b0 = 0; b0 < batch; b0 += per_launch) {
+          const dim3 grid((unsigned)team_size, (unsigned)std::min(per_launch, batch - b0));
+          if (bw == 2) hipLaunchKernelGGL(trd_band_kernel<2>, grid, dim3(256), 0, s, desc, w, b0);
+          else hipLaunchKernelGGL(trd_band_kernel<4>, grid, dim3(256), 0, s, desc, w, b0);
+        }
+      }));
+    }
+    int64_t bytes = 0;
+    for (int b = 0; b < batch; ++b) bytes += 2 * 8 * h_n[b] * h_n[b];
+    ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, bytes);
+    const size_t chase_lds = (size_t)n_max * 2 * bw * sizeof(double);
+    if (bw == 2) hipLaunchKernelGGL(trd_chase_kernel<2>, dim3(1, B), dim3(1024), chase_lds, s, desc, w);
+    else hipLaunchKernelGGL(trd_chase_kernel<4>, dim3(1, B), dim3(1024), chase_lds, s, desc, w);
+    const int kk = (int)std::min(k_max, n_max);
+    hipLaunchKernelGGL(trd_bisect_kernel, dim3(ndmps::ceil_div(kk, 4), B), dim3(256),
+                       (size_t)ndmps::round_up(n_max, 16) * 16, s, desc, w, kk);
+    NDMPS_LAUNCH_CHECK();
+    return NDMPS_OK;
+  }
   void* span = ndmps::span_begin(s);
   int64_t span_bytes = 0;  // algorithmic: every trailing element read once and written once per column
   if (team) {
@@ -2023,6 +2091,12 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
     hipLaunchKernelGGL(trd_ortho_kernel<true>, dim3(1, B), dim3(512), (size_t)2 * k16 * (k16 + 1) * 8, s, desc, w);
   else
     hipLaunchKernelGGL(trd_ortho_kernel<false>, dim3(1, B), dim3(512), (size_t)k16 * (k16 + 1) * 8, s, desc, w);
+  const int bw = band_width_for(n_max);
+  if (bw) {  // eigenvectors of T -> eigenvectors of the band matrix: the bulge chase's reflectors, sweeps in reverse
+    const dim3 grid((unsigned)ndmps::ceil_div(std::min<int64_t>(k16, w.kp), 32), B);
+    if (bw == 2) hipLaunchKernelGGL(trd_back2_kernel<2>, grid, dim3(1024), (size_t)n_max * 32 * 8, s, desc, w, kk);
+    else hipLaunchKernelGGL(trd_back2_kernel<4>, grid, dim3(1024), (size_t)n_max * 32 * 8, s, desc, w, kk);
+  }
   const int cols = std::max(kk, k_fill);
   // rows per lane of the back-transform: n <= SEG * R; RB reflectors of SEG * R doubles per LDS block
   const int per32 = (int)ndmps::ceil_div(n_max, 32), per64 = (int)ndmps::ceil_div(n_max, 64);

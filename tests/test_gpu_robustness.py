@@ -145,3 +145,40 @@ def test_more_groups_than_hardware_queues_take_turns_without_stalling(lib):
     for j in range(0, len(recs), 4):  # every group encoded the same four volumes
         assert float((recs[j] - ref).norm() / ref.norm()) < 1e-6
     assert objs[0].bond_sizes() == [8, 32, 32, 32, 32, 8]
+
+
+@pytest.mark.parametrize("bw", ["2", "4"])
+def test_two_stage_reduction_gives_lapacks_eigenpairs(lib, bw, monkeypatch):
+    """The optional two-stage tridiagonalisation (csrc/eig_band.inc, NDMPS_TRD_BAND=2|4: dense -> band with one
+    exchange per panel, bulge chase, two back-transformations) on graded Gram matrices, mixed orders in one batch,
+    against LAPACK.  Not the default path (measured slower than the one-stage kernel at order 512)."""
+    monkeypatch.setenv("NDMPS_TRD_BAND", bw)
+    rng = np.random.default_rng(11)
+    orders = [512, 384, 200, 137]
+    n_max, k = max(orders), 24
+    g = np.zeros((len(orders), n_max, n_max))
+    mats = []
+    for b, n in enumerate(orders):
+        x = rng.standard_normal((2 * n, n)) * np.logspace(0, -5, n)
+        mats.append(x.T @ x)
+    flat = torch.zeros((len(orders), n_max * n_max), dtype=torch.float64, device=DEV)
+    for b, (n, m) in enumerate(zip(orders, mats)):
+        flat[b, : n * n] = torch.from_numpy(m.reshape(-1)).to(DEV)
+    v = torch.zeros_like(flat)
+    w = torch.zeros((len(orders), n_max), dtype=torch.float64, device=DEV)
+    nbytes = int(lib.ndmps_syevd_topk_workspace_bytes(n_max, len(orders), k))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    sizes = _lib.i64_array(orders)
+    _lib.check(lib.ndmps_syevd_topk_values_f64(len(orders), flat.data_ptr(), n_max * n_max, sizes, v.data_ptr(), n_max * n_max,
+                                               w.data_ptr(), n_max, k, ws.data_ptr(), nbytes, _lib.stream_ptr()))
+    status = (C.c_int * len(orders))()
+    _lib.check(lib.ndmps_syevd_topk_vectors_f64(len(orders), sizes, _lib.i64_array([k] * len(orders)), k, ws.data_ptr(),
+                                                nbytes, status, _lib.stream_ptr()))
+    assert list(status) == [0] * len(orders)
+    wv, vv = w.cpu().numpy(), v.cpu().numpy()
+    for b, (n, m) in enumerate(zip(orders, mats)):
+        ref = np.linalg.eigvalsh(m)[::-1]
+        assert np.allclose(wv[b, :k], ref[:k], rtol=0, atol=2e-14 * ref[0])
+        vk = vv[b, : n * n].reshape(n, n)[:, :k]
+        assert np.abs(vk.T @ vk - np.eye(k)).max() < 1e-12
+        assert np.abs(m @ vk - vk * wv[b, :k]).max() < 1e-12 * ref[0]
