@@ -797,6 +797,12 @@ struct Gram128Geom {
   int slabs_off, slabs_diag;
   int64_t rows_off, rows_diag;
   int slots;  // workgroups = partial tiles per matrix
+  // XCD-aware order (xcd != 0, 1-D grid): a GROUP = the tiles_1d^2 workgroups that read the same two off-diagonal slabs
+  // (= one diagonal slab, rows_diag = 2 rows_off) of one matrix, i.e. the same rows of every 128-column panel.
+  // Workgroups are dealt round-robin over the 8 XCDs, so the group's members take hardware ids that are 8 apart and
+  // consecutive on their XCD: they start together on one XCD and stream the same rows through ONE L2 (each panel
+  // was fetched by the four tiles sharing it from four different XCDs otherwise: 4 x the fabric traffic).
+  int xcd, members, groups_per_matrix, groups_total;
 };
 struct Gram128Ptrs {
   const void* a[kGram128MaxBatch];
@@ -846,8 +852,24 @@ __global__ void __launch_bounds__(256, 2)
 gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __restrict__ partial, Gram128Geom g,
                int vec_ok, const int64_t* __restrict__ row_off, const int64_t* __restrict__ col_off) {
   extern __shared__ __attribute__((aligned(16))) float g128_lds[];  // [2 buffers][2 panels][GW_KB][G128_LD]
-  const TIN* __restrict__ A = static_cast<const TIN*>(ptrs.a[blockIdx.y]);
-  const int id = blockIdx.x;
+  int id = blockIdx.x, vol = blockIdx.y;
+  if (g.xcd) {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int group = (q / g.members) * 8 + x, mem = q % g.members;
+    if (group >= g.groups_total) return;
+    vol = group / g.groups_per_matrix;
+    const int sp = group % g.groups_per_matrix;
+    if (g.xcd == 2) {  // one slab per group, diagonal slabs as long as the others
+      id = mem < g.n_off ? mem * g.slabs_off + sp : g.n_off * g.slabs_off + (mem - g.n_off) * g.slabs_diag + sp;
+    } else if (mem < 2 * g.n_off) {
+      const int sl = 2 * sp + mem / g.n_off;
+      if (sl >= g.slabs_off) return;
+      id = (mem % g.n_off) * g.slabs_off + sl;
+    } else {
+      id = g.n_off * g.slabs_off + (mem - 2 * g.n_off) * g.slabs_diag + sp;
+    }
+  }
+  const TIN* __restrict__ A = static_cast<const TIN*>(ptrs.a[vol]);
   int ti, tj, slab;
   int64_t rows;
   if (id < g.n_off * g.slabs_off) {
@@ -972,7 +994,7 @@ gram128_kernel(Gram128Ptrs ptrs, int64_t m, int64_t n, int64_t lda, double* __re
     b_col = 64;
   }
 
-  double* out = partial + ((int64_t)blockIdx.y * g.slots + id) * (128 * 128);
+  double* out = partial + ((int64_t)vol * g.slots + id) * (128 * 128);
   // one copy of the chunk loop per role (the role is fixed for the life of the wave; a branch per chunk made
   // the register allocator keep the accumulators three times)
   auto run = [&](auto role_tag) {
@@ -1343,6 +1365,29 @@ Gram128Geom gram128_geometry(int64_t m, int64_t n, int batch) {
   g.rows_diag = ndmps::round_up((g.rows_off * 8 + 4) / 5, GW_KB);
   g.slabs_off = (int)ndmps::ceil_div(m, g.rows_off);
   g.slabs_diag = (int)ndmps::ceil_div(m, g.rows_diag);
+  g.xcd = 0;
+  g.members = g.groups_per_matrix = g.groups_total = 0;
+  // big batched launches (the ones that take the device-side turn): XCD-aware groups, diagonal slabs of exactly two
+  // off-diagonal slabs (a diagonal workgroup then does 2 x 10 / 16 of an off-diagonal one's MFMA work)
+  const char* xe = getenv("NDMPS_GRAM_XCD");
+  const int xmode = xe ? atoi(xe) : 0;
+  if (batch > 1 && g.tiles_1d >= 2 && g.slabs_off >= 4 && xmode == 1) {
+    g.rows_diag = 2 * g.rows_off;
+    g.slabs_diag = (int)ndmps::ceil_div(m, g.rows_diag);
+    g.xcd = 1;
+    g.members = 2 * g.n_off + g.n_diag;
+    g.groups_per_matrix = g.slabs_diag;
+    g.groups_total = batch * g.groups_per_matrix;
+  } else if (batch > 1 && g.tiles_1d >= 2 && g.slabs_off >= 4 && xmode == 2) {
+    // as many workgroups as before: slabs longer by (n_off + 0.625 n_diag) / (n_off + n_diag)
+    const int64_t s2 = std::max<int64_t>(1, (int64_t)(g.slabs_off * weight / (g.n_off + g.n_diag) + 0.5));
+    g.rows_off = g.rows_diag = ndmps::round_up(ndmps::ceil_div(m, s2), GW_KB);
+    g.slabs_off = g.slabs_diag = (int)ndmps::ceil_div(m, g.rows_off);
+    g.xcd = 2;
+    g.members = g.n_off + g.n_diag;
+    g.groups_per_matrix = g.slabs_off;
+    g.groups_total = batch * g.groups_per_matrix;
+  }
   g.slots = g.n_off * g.slabs_off + g.n_diag * g.slabs_diag;
   return g;
 }
@@ -1408,8 +1453,16 @@ int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int6
     const bool interior = vec_ok && n % 128 == 0 && m % GW_KB == 0 && g.rows_off % GW_KB == 0 && g.rows_diag % GW_KB == 0 &&
                           !getenv("NDMPS_GRAM_GENERAL");
     auto kernel = !interior ? gram128_kernel<TIN, 0> : (d_row_off ? gram128_kernel<TIN, 2> : gram128_kernel<TIN, 1>);
-    hipLaunchKernelGGL(kernel, dim3(g.slots, count), dim3(256), kGram128Lds, s, ptrs, m, n, lda,
-                       partial + (int64_t)base * g.slots * 16384, g, vec_ok, d_row_off, d_col_off);
+    if (g.xcd) {
+      Gram128Geom gc = g;  // this launch's matrices
+      gc.groups_total = count * g.groups_per_matrix;
+      const unsigned wgs = (unsigned)(ndmps::ceil_div(gc.groups_total, 8) * g.members * 8);
+      hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), kGram128Lds, s, ptrs, m, n, lda,
+                         partial + (int64_t)base * g.slots * 16384, gc, vec_ok, d_row_off, d_col_off);
+    } else {
+      hipLaunchKernelGGL(kernel, dim3(g.slots, count), dim3(256), kGram128Lds, s, ptrs, m, n, lda,
+                         partial + (int64_t)base * g.slots * 16384, g, vec_ok, d_row_off, d_col_off);
+    }
   }
   // algorithmic work of the span: the upper triangle incl. the diagonal, 2 flops per product
   ndmps::span_end(span, s, turn ? ndmps::kSpanGram : ndmps::kSpanGramSmall, (batch + kGram128MaxBatch - 1) / kGram128MaxBatch,
