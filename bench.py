@@ -173,7 +173,7 @@ def synthetic_mri_device(shape, seed, device):
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r0*_pmc_summary.json, written
-    by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; the newest round that has the kernel),
+    by tools/pmc_to_json.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; the newest round that has the kernel),
     or None."""
     for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:

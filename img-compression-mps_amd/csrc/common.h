@@ -83,7 +83,7 @@ void span_end(void* begin, hipStream_t s, int slot, int64_t launches, int64_t by
 constexpr int kTurnTeam = 0, kTurnGram = 1;
 class Turn {
  public:
-  Turn(hipStream_t s, int which) : s_(s), which_(which) {}
+  Turn(hipStream_t s, int which, unsigned weight = 1, unsigned cap = 1) : s_(s), which_(which), weight_(weight), cap_(cap) {}
   ~Turn();
   Turn(const Turn&) = delete;
   Turn& operator=(const Turn&) = delete;
@@ -93,8 +93,8 @@ class Turn {
  private:
   hipStream_t s_;
   int which_;
-  void* dev_ = nullptr;  // per-device turn state while the turn is open
-  unsigned ticket_ = 0;
+  unsigned weight_, cap_;  // units asked for / units there are
+  void* dev_ = nullptr;    // per-device turn state while the turn is open
 };
 
 }  // namespace ndmps

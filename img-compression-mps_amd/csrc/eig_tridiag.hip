@@ -1894,8 +1894,9 @@ int team_slots(int& slots) {
 // At most one team kernel in flight per device (see trd_team_kernel); the turn is taken on the device
 // (ndmps::Turn, util.hip).
 template <typename F>
-int team_launch(hipStream_t s, F&& launch) {
-  ndmps::Turn turn(s, ndmps::kTurnTeam);
+int team_launch(hipStream_t s, F&& launch, bool half = false) {
+  // a launch that fills one workgroup slot per CU takes half the turn: two of them fit the GPU together
+  ndmps::Turn turn(s, ndmps::kTurnTeam, half && !getenv("NDMPS_TEAM_FULL_TURN") ? 1u : 2u, 2u);
   NDMPS_TRY(turn.begin());
   launch();
   return turn.end();
@@ -2004,7 +2005,7 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
         else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, w, b0, epoch);
         else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, w, b0, epoch);
       }
-    }));
+    }, narrow_team || (int64_t)std::min(per_launch, batch) * team_size <= slots / 2));
     // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
     for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
     ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, span_bytes);

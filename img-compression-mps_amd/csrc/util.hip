@@ -198,23 +198,30 @@ extern "C" int ndmps_profile_collect(int slot, double* h_ms, int64_t* h_launches
 // from turn begin to turn end, for every kind of turn (two mutexes would still allow a cycle through two locks).  In
 // any queue an owner's release then has only its own acquire and its own kernels in front of it, which end by
 // themselves, so every spinner is released in finite time whatever the stream-to-queue map is.
-// The lock word holds the owner's ticket: a spinner that gave up after kTurnSpinTicks (bounded like every wait here)
-// runs unowned and its release leaves the real owner's lock alone.
+// Every wait is bounded (kTurnSpinTicks): a spinner that gave up takes its units regardless.
 namespace {
 constexpr long long kTurnSpinTicks = 300000000LL;  // 3 s of the 100 MHz wall clock
-__global__ void turn_acquire_kernel(unsigned* __restrict__ lock, unsigned ticket) {
+// The lock word counts the UNITS in use; a turn asks for `weight` units of `cap` (team launches: 2 of 2 when they fill
+// both workgroup slots of every CU, 1 of 2 when they fill one -- two such launches fit the GPU together and leave a
+// slot per CU to everybody else; Gram launches: 1 of 1).  A spinner that gave up after kTurnSpinTicks takes its units
+// regardless, so every release subtracts what its acquire added.
+__global__ void turn_acquire_kernel(unsigned* __restrict__ lock, unsigned weight, unsigned cap) {
   const long long t0 = wall_clock64();
-  while (atomicCAS(lock, 0u, ticket) != 0u) {
-    if (wall_clock64() - t0 > kTurnSpinTicks) break;
+  for (;;) {
+    const unsigned c = __hip_atomic_load(lock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c + weight <= cap && atomicCAS(lock, c, c + weight) == c) return;
+    if (wall_clock64() - t0 > kTurnSpinTicks) {
+      atomicAdd(lock, weight);
+      return;
+    }
     __builtin_amdgcn_s_sleep(8);
   }
 }
-__global__ void turn_release_kernel(unsigned* __restrict__ lock, unsigned ticket) { atomicCAS(lock, ticket, 0u); }
+__global__ void turn_release_kernel(unsigned* __restrict__ lock, unsigned weight) { atomicSub(lock, weight); }
 
 struct TurnDevice {
   unsigned* base = nullptr;  // 256 bytes per device, once: the only allocation outside ndmps_plan_create
   std::mutex submit;         // held while a turn is being enqueued
-  unsigned next_ticket = 1;
 };
 TurnDevice g_turn[64];
 std::mutex g_turn_alloc;
@@ -246,9 +253,7 @@ int Turn::begin() {
   NDMPS_TRY(turn_device(&td));
   td->submit.lock();
   dev_ = td;
-  ticket_ = td->next_ticket++;
-  if (td->next_ticket == 0) td->next_ticket = 1;  // 0 means "free"
-  hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(1), 0, s_, td->base + 16 * which_, ticket_);  // words 64 B apart
+  hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(1), 0, s_, td->base + 16 * which_, weight_, cap_);  // words 64 B apart
   if (hipGetLastError() != hipSuccess) {
     dev_ = nullptr;
     td->submit.unlock();
@@ -262,7 +267,7 @@ int Turn::end() {
   if (!dev_) return NDMPS_OK;
   TurnDevice* td = (TurnDevice*)dev_;
   dev_ = nullptr;
-  hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(1), 0, s_, td->base + 16 * which_, ticket_);
+  hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(1), 0, s_, td->base + 16 * which_, weight_);
   const hipError_t e = hipGetLastError();
   td->submit.unlock();
   if (e != hipSuccess) {
