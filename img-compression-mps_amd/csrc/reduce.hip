@@ -308,14 +308,16 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
       }
     }
     wave_lds_sync();
-    for (int Ns = 1; Ns < M;) {
-      const int R = ((M / Ns) % 4 == 0) ? 4 : 2;
+    const int lm = 31 - __builtin_clz(M);  // M = 2^lm
+    for (int ls = 0; ls < lm;) {           // Ns = 2^ls: length of the finished sub-transforms
+      const int Ns = 1 << ls;
+      const int lr = (lm - ls) >= 2 ? 2 : 1, R = 1 << lr;
       if (on) {
-        const int span = M / R;
+        const int span = M >> lr;
         for (int j = lane; j < span; j += 64) {
-          const int k = j % Ns;
-          const int j0 = (j / Ns) * R * Ns + k;
-          const int tstep = k * (M / (R * Ns));
+          const int k = j & (Ns - 1);
+          const int j0 = ((j >> ls) << (ls + lr)) + k;
+          const int tstep = k << (lm - lr - ls);
           if (R == 4) {
             Cf v0 = a[j], v1 = a[j + span], v2 = a[j + 2 * span], v3 = a[j + 3 * span];
             Cf t1 = twM[tstep], t2 = twM[2 * tstep], t3 = twM[3 * tstep];
@@ -347,7 +349,7 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
       Cf* sw = a;
       a = b;
       b = sw;
-      Ns *= R;
+      ls += lr;
     }
     if (on) {
       if (!INVERSE) {
@@ -389,7 +391,11 @@ template <bool INVERSE>
 int dct_fft_launch(const float* src, float* dst, int64_t rows, int64_t n, hipStream_t s) {
   const int M = (int)n / 2;
   const size_t lds = (size_t)(M + 2 * (M + 1)) * sizeof(Cf) + (size_t)4 * (n + 4 * M) * sizeof(float);
-  const int grid = (int)std::min<int64_t>((rows + 3) / 4, (int64_t)ndmps::kNumCU * 8);
+  // exactly the workgroups the device keeps resident at once (every workgroup loops over rows: a partly filled second
+  // round of workgroups would leave a third of the GPU idle for half the kernel)
+  int per_cu = 0;
+  NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dct_fft_kernel<INVERSE>, 256, lds));
+  const int grid = (int)std::min<int64_t>((rows + 3) / 4, (int64_t)ndmps::kNumCU * std::max(per_cu, 1));
   hipLaunchKernelGGL(dct_fft_kernel<INVERSE>, dim3(grid), dim3(256), lds, s, src, dst, rows, (int)n);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
