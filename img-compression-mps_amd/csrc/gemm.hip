@@ -656,10 +656,10 @@ __device__ __forceinline__ float4 load4_as_f32(const __bf16* p) {
 // the matrix is the C-order volume read through the index permutation (see GemmIndex); with vec_ok every aligned
 // group of four columns has consecutive offsets.
 template <int GW_TS, typename TIN>
-__global__ void __launch_bounds__(256, 2)
-gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
-                 double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab, int vec_ok,
-                 const int64_t* __restrict__ row_off = nullptr, const int64_t* __restrict__ col_off = nullptr) {
+__device__ __forceinline__ void gram_wide_body(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+                                               double* __restrict__ out, int n_tiles_1d, int64_t rows_per_slab, int vec_ok,
+                                               const int64_t* __restrict__ row_off, const int64_t* __restrict__ col_off,
+                                               int tile_id, int slab_id) {
   constexpr int GW_LD = GW_TS + 16;
   constexpr int NT = GW_TS / 32;       // MFMA tiles per wave and direction
   constexpr int SUB = GW_TS / 2;       // wave sub-tile edge
@@ -668,7 +668,7 @@ gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
   __shared__ float Ai[GW_KB][GW_LD];
   __shared__ float Aj[GW_KB][GW_LD];
 
-  int tile = blockIdx.x, ti = 0;
+  int tile = tile_id, ti = 0;
   while (tile >= n_tiles_1d - ti) {
     tile -= n_tiles_1d - ti;
     ++ti;
@@ -676,7 +676,7 @@ gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
   const int tj = ti + tile;
   const bool diag = ti == tj;
   const int64_t i0 = (int64_t)ti * GW_TS, j0 = (int64_t)tj * GW_TS;
-  const int64_t r_begin = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r_begin = (int64_t)slab_id * rows_per_slab;
   const int64_t r_end = min(m, r_begin + rows_per_slab);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -758,7 +758,6 @@ gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
     }
   }
 
-  double* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GW_TS * GW_TS);
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -768,6 +767,55 @@ gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
         const int rr = wr * SUB + 16 * a + lr + 4 * reg, cc = wc * SUB + 16 * b + lc;
         out[rr * GW_TS + cc] = acc[a][b][reg];
       }
+}
+
+template <int GW_TS, typename TIN>
+__global__ void __launch_bounds__(256, 2)
+gram_wide_kernel(const TIN* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+                 double* __restrict__ partial, int n_tiles_1d, int64_t rows_per_slab, int vec_ok,
+                 const int64_t* __restrict__ row_off = nullptr, const int64_t* __restrict__ col_off = nullptr) {
+  gram_wide_body<GW_TS, TIN>(A, m, n, lda, partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GW_TS * GW_TS),
+                             n_tiles_1d, rows_per_slab, vec_ok, row_off, col_off, blockIdx.x, blockIdx.y);
+}
+
+// The same tiles for a whole lockstep group in ONE launch (blockIdx.z = matrix): the 64-column raw Gram of a bond cap
+// of 32 (BASELINE configs 2 and 4) went out as one launch per volume, each cut into 512 short slabs to fill the GPU by
+// itself (16.8 MB of partial tiles written and read back per 64 MB volume); a group shares the GPU, so slabs are long.
+struct GramBatchPtrs {
+  const void* a[64];
+};
+template <int GW_TS, typename TIN>
+__global__ void __launch_bounds__(256, 2)
+gram_wide_batched_kernel(GramBatchPtrs ptrs, int64_t m, int64_t n, int64_t lda, double* __restrict__ partial, int n_tiles_1d,
+                         int64_t rows_per_slab, int vec_ok, const int64_t* __restrict__ row_off,
+                         const int64_t* __restrict__ col_off) {
+  double* out = partial + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (GW_TS * GW_TS);
+  gram_wide_body<GW_TS, TIN>(static_cast<const TIN*>(ptrs.a[blockIdx.z]), m, n, lda, out, n_tiles_1d, rows_per_slab, vec_ok,
+                             row_off, col_off, blockIdx.x, blockIdx.y);
+}
+// G of matrix blockIdx.z: its slabs of tile blockIdx.x summed in order; upper part mirrored; optional un-permutation
+template <int TS>
+__global__ void __launch_bounds__(256)
+tile_reduce_batched_kernel(const double* __restrict__ partial, int n_slabs, int n_tiles_1d, int n_tiles, double* __restrict__ G,
+                           int64_t stride_G, int64_t n, const int32_t* __restrict__ perm) {
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= TS * TS) return;
+  const double* src = partial + ((int64_t)blockIdx.z * n_slabs * n_tiles + blockIdx.x) * (TS * TS) + e;
+  double s = 0.0;
+  for (int sl = 0; sl < n_slabs; ++sl) s += src[(int64_t)sl * n_tiles * (TS * TS)];
+  int tile = blockIdx.x, ti = 0;
+  while (tile >= n_tiles_1d - ti) {
+    tile -= n_tiles_1d - ti;
+    ++ti;
+  }
+  const int tj = ti + tile;
+  const int64_t r = (int64_t)ti * TS + e / TS, c = (int64_t)tj * TS + e % TS;
+  if (r < n && c < n && (ti != tj || c >= r)) {
+    double* Gb = G + (int64_t)blockIdx.z * stride_G;
+    const int64_t pr = perm ? perm[r] : r, pc = perm ? perm[c] : c;
+    Gb[pr * n + pc] = s;
+    Gb[pc * n + pr] = s;
+  }
 }
 
 // ----------------------------------------------------------------------------------
@@ -1565,18 +1613,80 @@ extern "C" int ndmps_gram_indexed_f32(const float* d_base, int64_t m, int64_t n,
 
 // Batched Gram of `batch` matrices of one shape (n >= 128, m >= 256): h_A[b] (host array of device pointers) ->
 // d_G + b stride_G.  One launch for the whole batch (what a lockstep group of volumes needs at a site).
+namespace {
+// 64 <= n < 128: 64 x 64 tiles (gram_wide_body<64>), slabs sized for ~8 workgroups per CU over the whole group
+inline bool gram_use_wide_batched(int batch, int64_t m, int64_t n) { return batch >= 2 && n >= 64 && n < 128 && m >= 256; }
+struct GramWideBatchGeom {
+  int tiles_1d, n_tiles, n_slabs;
+  int64_t rows_per_slab;
+};
+GramWideBatchGeom gram_wide_batched_geometry(int batch, int64_t m, int64_t n) {
+  GramWideBatchGeom g;
+  g.tiles_1d = (int)ndmps::ceil_div(n, 64);
+  g.n_tiles = g.tiles_1d * (g.tiles_1d + 1) / 2;
+  const int64_t want = std::max<int64_t>(1, ndmps::ceil_div((int64_t)8 * ndmps::kNumCU, (int64_t)batch * g.n_tiles));
+  g.rows_per_slab = ndmps::round_up(std::max<int64_t>(ndmps::ceil_div(m, want), 4 * GW_KB), GW_KB);
+  g.n_slabs = (int)std::max<int64_t>(1, ndmps::ceil_div(m, g.rows_per_slab));
+  return g;
+}
+template <typename TIN>
+int gram_wide_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int64_t lda, double* d_G, int64_t stride_G,
+                      void* d_ws, int64_t ws_bytes, hipStream_t s, const int64_t* d_row_off, const int64_t* d_col_off,
+                      const int32_t* d_perm) {
+  NDMPS_REQUIRE(h_A && d_G && lda >= n && stride_G >= n * n, "bad batched Gram argument");
+  const GramWideBatchGeom g = gram_wide_batched_geometry(batch, m, n);
+  const int64_t need = (int64_t)batch * g.n_slabs * g.n_tiles * 4096 * 8 + 256;
+  if (!d_ws || ws_bytes < need) {
+    ndmps::set_error("Gram workspace too small: %lld < %lld", (long long)ws_bytes, (long long)need);
+    return NDMPS_EWORKSPACE;
+  }
+  int vec_ok = (lda % 4 == 0 && n % 4 == 0) ? 1 : 0;
+  for (int b = 0; b < batch; ++b) {
+    NDMPS_REQUIRE(h_A[b], "NULL Gram operand %d", b);
+    if ((uintptr_t)h_A[b] % (4 * sizeof(TIN)) != 0) vec_ok = 0;
+  }
+  if (d_row_off) NDMPS_REQUIRE(d_col_off && vec_ok, "gathered Gram needs n %% 4 == 0 and aligned bases");
+  double* partial = (double*)d_ws;
+  void* span = ndmps::span_begin(s);
+  for (int base = 0; base < batch; base += 64) {
+    const int count = std::min(64, batch - base);
+    GramBatchPtrs ptrs;
+    for (int t = 0; t < count; ++t) ptrs.a[t] = h_A[base + t];
+    double* part = partial + (int64_t)base * g.n_slabs * g.n_tiles * 4096;
+    hipLaunchKernelGGL((gram_wide_batched_kernel<64, TIN>), dim3(g.n_tiles, g.n_slabs, count), dim3(256), 0, s, ptrs, m, n, lda,
+                       part, g.tiles_1d, g.rows_per_slab, vec_ok, d_row_off, d_col_off);
+    hipLaunchKernelGGL(tile_reduce_batched_kernel<64>, dim3(g.n_tiles, 16, count), dim3(256), 0, s, part, g.n_slabs, g.tiles_1d,
+                       g.n_tiles, d_G + (int64_t)base * stride_G, stride_G, n, d_perm);
+  }
+  ndmps::span_end(span, s, ndmps::kSpanGramSmall, (batch + 63) / 64, (int64_t)batch * m * n * (n + 1));
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+}  // namespace
+
 extern "C" int64_t ndmps_gram_batched_workspace_bytes(int batch, int64_t m, int64_t n) {
-  if (batch <= 0 || !gram_use_128(m, n)) return 0;
-  return gram128_workspace(m, n, batch);
+  if (batch <= 0) return 0;
+  if (gram_use_128(m, n)) return gram128_workspace(m, n, batch);
+  if (gram_use_wide_batched(batch, m, n)) {
+    const GramWideBatchGeom g = gram_wide_batched_geometry(batch, m, n);
+    return (int64_t)batch * g.n_slabs * g.n_tiles * 4096 * 8 + 256;
+  }
+  return 0;
 }
 extern "C" int ndmps_gram_batched_f32(int batch, const float* const* h_A, int64_t m, int64_t n, int64_t lda,
                                       double* d_G, int64_t stride_G, void* d_ws, int64_t ws_bytes,
                                       ndmps_stream_t stream) {
+  if (!gram_use_128(m, n) && gram_use_wide_batched(batch, m, n))
+    return gram_wide_batched<float>(batch, h_A, m, n, lda, d_G, stride_G, d_ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr,
+                                    nullptr);
   return gram128_batched<float>(batch, h_A, m, n, lda, d_G, stride_G, d_ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr);
 }
 extern "C" int ndmps_gram_batched_bf16(int batch, const void* const* h_A, int64_t m, int64_t n, int64_t lda,
                                        double* d_G, int64_t stride_G, void* d_ws, int64_t ws_bytes,
                                        ndmps_stream_t stream) {
+  if (!gram_use_128(m, n) && gram_use_wide_batched(batch, m, n))
+    return gram_wide_batched<__bf16>(batch, (const __bf16* const*)h_A, m, n, lda, d_G, stride_G, d_ws, ws_bytes,
+                                     (hipStream_t)stream, nullptr, nullptr, nullptr);
   return gram128_batched<__bf16>(batch, (const __bf16* const*)h_A, m, n, lda, d_G, stride_G, d_ws, ws_bytes,
                                  (hipStream_t)stream, nullptr, nullptr);
 }
@@ -1585,6 +1695,9 @@ extern "C" int ndmps_gram_batched_indexed_f32(int batch, const float* const* h_b
                                               const int32_t* d_col_perm, double* d_G, int64_t stride_G, void* d_ws,
                                               int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_row_off && d_col_off, "NULL offset table");
+  if (!gram_use_128(m, n) && gram_use_wide_batched(batch, m, n))
+    return gram_wide_batched<float>(batch, h_base, m, n, n, d_G, stride_G, d_ws, ws_bytes, (hipStream_t)stream, d_row_off,
+                                    d_col_off, d_col_perm);
   return gram128_batched<float>(batch, h_base, m, n, n, d_G, stride_G, d_ws, ws_bytes, (hipStream_t)stream, d_row_off,
                                 d_col_off, d_col_perm);
 }

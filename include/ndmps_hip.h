@@ -181,7 +181,8 @@ int64_t ndmps_gemm_bf16_workspace_bytes(int transB, int64_t n, int64_t k);
 int ndmps_gemm_bf16(int transB, int64_t m, int64_t n, int64_t k, const void* d_A, int64_t lda,
                     const void* d_B, int64_t ldb, void* d_C, int64_t ldc, void* d_ws, int64_t ws_bytes,
                     ndmps_stream_t stream);
-/* The same for `batch` matrices of one shape in ONE launch (n >= 128, m >= 256; what a lockstep group of
+/* The same for `batch` matrices of one shape in ONE launch (m >= 256 and n >= 128, or 64 <= n < 128 with at least
+ * two matrices: _workspace_bytes returns 0 for shapes without a group-wide launch; what a lockstep group of
  * volumes needs at a site of the sweep, core/ndmps.py:74 per volume in the reference): h_A is a HOST array of
  * device pointers, G of matrix b goes to d_G + b * stride_G.  _indexed: element (r, c) of matrix b is
  * h_base[b][d_row_off[r] + d_col_off[c]] (see ndmps_gram_indexed_f32). */

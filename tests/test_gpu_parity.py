@@ -212,9 +212,10 @@ def test_gemm_batched_equals_gemm_per_triple(batch, m, n, k, ta, tb):
 
 
 @pytest.mark.parametrize("batch,m,n", [(1, 4096, 512), (3, 1000, 200), (5, 300, 128), (32, 512, 512), (2, 20000, 384),
-                                       (4, 257, 131)])
+                                       (4, 257, 131), (32, 32768, 64), (3, 5000, 64), (2, 300, 100), (70, 700, 96)])
 def test_gram_batched_fp64(batch, m, n):
-    """One launch for the Gram matrices of a group (n >= 128): exactly symmetric, fp64-accurate, and reproducible
+    """One launch for the Gram matrices of a group (n >= 128: 128 x 128 tiles; 64 <= n < 128 and at least two
+    matrices: 64 x 64 tiles, the raw Gram of a bond cap of 32): exactly symmetric, fp64-accurate, and reproducible
     (a second call gives the same bits)."""
     lib = _lib.load()
     rng = np.random.default_rng(batch + m + n)
@@ -234,7 +235,8 @@ def test_gram_batched_fp64(batch, m, n):
         got = g[b].cpu().numpy()
         assert np.array_equal(got, got.T)
         assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
-    assert lib.ndmps_gram_batched_workspace_bytes(batch, m, 64) == 0  # narrower matrices: ndmps_gram_f32 per matrix
+    assert lib.ndmps_gram_batched_workspace_bytes(batch, m, 48) == 0  # narrower matrices: ndmps_gram_f32 per matrix
+    assert lib.ndmps_gram_batched_workspace_bytes(1, m, 64) == 0      # a lone 64-column matrix as well
 
 
 def _syevj(lib, g):
@@ -1513,7 +1515,7 @@ def test_degenerate_inputs_match_the_oracle(name, kw):
         assert np.abs(rg - x).max() <= 2e-6 * scale
 
 
-@pytest.mark.parametrize("m,n,batch", [(4096, 512, 1), (2048, 256, 3), (1024, 96, 1), (600, 64, 1)])
+@pytest.mark.parametrize("m,n,batch", [(4096, 512, 1), (2048, 256, 3), (1024, 96, 1), (600, 64, 1), (8192, 64, 5), (900, 96, 2)])
 def test_gathered_gram_stores_its_result_through_the_column_permutation(m, n, batch):
     """The raw Gram of the fused sweep visits the columns in memory order (d_col_off ascending) and its slab
     reduction stores entry (a, b) at G[perm[a]][perm[b]]: the result equals the Gram of the gathered matrix with
