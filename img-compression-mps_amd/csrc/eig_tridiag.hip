@@ -1476,6 +1476,139 @@ __global__ void __launch_bounds__(512) trd_ortho_kernel(TrdDesc* __restrict__ de
   }
 }
 
+// k > 64 (BASELINE config 5: k = 128): the same orthonormalisation by COLUMN BLOCKS of 64 -- block classical
+// Gram-Schmidt with re-orthogonalisation: for every block, twice: project out the finished columns
+// (P = Z_prev^T Z_blk, Z_blk -= Z_prev P, both on the f64 MFMA), then the blocked Cholesky-QR of trd_ortho_kernel<true>
+// on the block.  The factors of one block (2 x 64 x 65 doubles) and P (64 x 65) fit the LDS; the whole 128 x 128
+// factor and its inverse do not (264 KB), which sent k = 128 to the column-by-column Cholesky (3.1 ms per call).
+__global__ void __launch_bounds__(512) trd_ortho_blocks_kernel(TrdDesc* __restrict__ desc, TrdWork w) {
+  constexpr int KB = 64, LDL = KB + 1;
+  TrdDesc& d = desc[blockIdx.y];
+  const int n = d.n, k = d.k, kp = w.kp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int64_t b = blockIdx.y;
+  double* Z = w.Z + b * w.n_max * kp;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Ls = lds;             // [64][65] Cholesky factor of the block
+  double* Li = lds + KB * LDL;  // [64][65] its inverse
+  double* Ps = Li + KB * LDL;   // [64][65] one 64-row slice of P
+  for (int c0 = 0; c0 < k; c0 += KB) {
+    const int kb = min(KB, k - c0), kb16 = (kb + 15) & ~15;
+    for (int pass = 0; pass < 2; ++pass) {
+      // ---- project out the finished columns, 64 of them at a time
+      for (int p0 = 0; p0 < c0; p0 += KB) {
+        for (int tile = wave; tile < (KB / 16) * (kb16 / 16); tile += 8) {
+          const int ta = tile / (kb16 / 16), tb = tile % (kb16 / 16);
+          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+          const double* za = Z + p0 + ta * 16 + li;
+          const double* zb = Z + c0 + tb * 16 + li;
+          const bool col_ok = tb * 16 + li < kb;
+          for (int i0 = 0; i0 < n; i0 += 32) {
+            double av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int i = i0 + 4 * u + lk;
+              const bool ok = i < n;
+              const int64_t o = (int64_t)(ok ? i : 0) * kp;
+              av[u] = ok ? za[o] : 0.0;
+              bv[u] = (ok && col_ok) ? zb[o] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ps[(ta * 16 + lk + 4 * r) * LDL + tb * 16 + li] = acc[r];
+        }
+        __syncthreads();
+        for (int rt = wave; rt * 16 < n; rt += 8) {
+          const int i0 = 16 * rt;
+          const bool row_ok = i0 + li < n;
+          double av[16];
+#pragma unroll
+          for (int s4 = 0; s4 < 16; ++s4) av[s4] = row_ok ? -Z[(int64_t)(i0 + li) * kp + p0 + 4 * s4 + lk] : 0.0;
+          for (int ct = 0; ct < kb16 / 16; ++ct) {
+            f64x4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = i0 + lk + 4 * r, cc = 16 * ct + li;
+              acc[r] = (i < n && cc < kb) ? Z[(int64_t)i * kp + c0 + cc] : 0.0;
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], Ps[(4 * s4 + lk) * LDL + 16 * ct + li], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = i0 + lk + 4 * r, cc = 16 * ct + li;
+              if (i < n && cc < kb) Z[(int64_t)i * kp + c0 + cc] = acc[r];
+            }
+          }
+        }
+        __syncthreads();
+      }
+      // ---- S = Z_blk^T Z_blk
+      const int nt = kb16 / 16, ntiles = nt * (nt + 1) / 2;
+      for (int tile = wave; tile < ntiles; tile += 8) {
+        int ta = 0, u0 = tile;
+        while (u0 >= nt - ta) {
+          u0 -= nt - ta;
+          ++ta;
+        }
+        const int tb = ta + u0;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* za = Z + c0 + ta * 16 + li;
+        const double* zb = Z + c0 + tb * 16 + li;
+        const bool a_ok = ta * 16 + li < kb, b_ok = tb * 16 + li < kb;
+        for (int i0 = 0; i0 < n; i0 += 32) {
+          double av[8], bv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 4 * u + lk;
+            const bool ok = i < n;
+            const int64_t o = (int64_t)(ok ? i : 0) * kp;
+            av[u] = (ok && a_ok) ? za[o] : 0.0;
+            bv[u] = (ok && b_ok) ? zb[o] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ra = ta * 16 + lk + 4 * r, cb = tb * 16 + li;
+          Ls[ra * LDL + cb] = acc[r];
+          Ls[cb * LDL + ra] = acc[r];
+        }
+      }
+      __syncthreads();
+      if (!chol_inv_blocked(Ls, Li, kb16, kb, LDL, tid) && tid == 0 && d.status != 2) d.status = 1;
+      // ---- Z_blk <- Z_blk L^-T
+      for (int rt = wave; rt * 16 < n; rt += 8) {
+        const int i0 = 16 * rt;
+        const bool row_ok = i0 + li < n;
+        double av[16];
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+          const int col = 4 * s4 + lk;
+          av[s4] = (row_ok && col < kb) ? Z[(int64_t)(i0 + li) * kp + c0 + col] : 0.0;
+        }
+        for (int ct = 0; ct < kb16 / 16; ++ct) {
+          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s4 = 0; s4 < 16; ++s4)
+            if (4 * s4 < 16 * (ct + 1) && 4 * s4 < kb16)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], Li[(16 * ct + li) * LDL + 4 * s4 + lk], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = i0 + lk + 4 * r, cc = 16 * ct + li;
+            if (i < n && cc < kb) Z[(int64_t)i * kp + c0 + cc] = acc[r];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ back-transform
 // V = H_0 H_1 ... H_{n-2} Z on k columns.  A column lives in the registers of SEG lanes (row i in lane
 // i mod SEG, slot i / SEG), so v^T z is a shuffle reduction and a reflector costs no barrier.  Reflectors
@@ -1855,6 +1988,8 @@ int trd_opt_in() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_ortho_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_ortho_blocks_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 65 * 8));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_back2_kernel<2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 8));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_back2_kernel<4>),
@@ -2090,6 +2225,8 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
                      std::max((size_t)n_max * 16, (size_t)2 * 4 * (w.kp <= 64 ? 32 : 16) * w.kp * 8), s, desc, w);
   if (k16 <= 64)
     hipLaunchKernelGGL(trd_ortho_kernel<true>, dim3(1, B), dim3(512), (size_t)2 * k16 * (k16 + 1) * 8, s, desc, w);
+  else if (!getenv("NDMPS_ORTHO_COLUMNS"))  // k > 64: column blocks of 64 (block Gram-Schmidt + blocked Cholesky-QR)
+    hipLaunchKernelGGL(trd_ortho_blocks_kernel, dim3(1, B), dim3(512), (size_t)3 * 64 * 65 * 8, s, desc, w);
   else
     hipLaunchKernelGGL(trd_ortho_kernel<false>, dim3(1, B), dim3(512), (size_t)k16 * (k16 + 1) * 8, s, desc, w);
   const int bw = band_width_for(n_max);

@@ -825,6 +825,32 @@ def test_topk_solver_degenerate_spectra():
         _check_topk(g, w, v, k, tol_scale=4.0, k_max=50)
 
 
+def test_topk_solver_more_than_64_vectors_by_column_blocks():
+    """k > 64 (BASELINE config 5 wants 128): the eigenvector block is orthonormalised in column blocks of 64 (block
+    Gram-Schmidt with re-orthogonalisation + blocked Cholesky-QR on the MFMA).  Ranks 65 .. 128 incl. ragged last
+    blocks, clusters that straddle the block boundary, exact multiplicities; the column-by-column path on the same
+    input as a cross-check."""
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    n = 300
+    q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    lam_cluster = np.r_[np.linspace(2.0, 1.0, 60), np.full(10, 0.5), np.linspace(0.4, 0.1, 230)]  # a 10-fold one over 64
+    lam_flat = np.r_[np.full(30, 1.0), np.linspace(0.9, 0.3, 60), np.zeros(210)]  # exact multiplicity, then an exact null space
+    a = rng.standard_normal((700, 512)) * np.logspace(0, -6, 512)[None, :]
+    mats = [(q * lam_cluster) @ q.T, (q * lam_flat) @ q.T, a.T @ a, np.eye(200) * 2.0]
+    mats = [0.5 * (g + g.T) for g in mats]
+    ks = [70, 88, 128, 65]
+    for g, k, (w, v) in zip(mats, ks, _topk(lib, mats, ks, k_max=128)):
+        _check_topk(g, w, v, k, tol_scale=8.0, k_max=128)
+    os.environ["NDMPS_ORTHO_COLUMNS"] = "1"
+    try:
+        old = _topk(lib, mats[2:3], [128], k_max=128)
+    finally:
+        del os.environ["NDMPS_ORTHO_COLUMNS"]
+    new = _topk(lib, mats[2:3], [128], k_max=128)
+    assert np.abs(old[0][1] @ old[0][1].T - new[0][1] @ new[0][1].T).max() <= 1e-9  # same subspace (gaps ~1e-12 |G|)
+
+
 def test_from_tensors_equals_from_tensor_one_by_one():
     vols = [synthetic_mri((32, 32, 32), seed=s) for s in (1, 2, 3)]
     vols[1] = vols[1] * 0.25  # different scales and spectra inside one batch
