@@ -785,7 +785,7 @@ struct GramBatchPtrs {
   const void* a[64];
 };
 template <int GW_TS, typename TIN>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 4)  // a 64-column Gram is a stream: four workgroups per CU keep more of it in flight
 gram_wide_batched_kernel(GramBatchPtrs ptrs, int64_t m, int64_t n, int64_t lda, double* __restrict__ partial, int n_tiles_1d,
                          int64_t rows_per_slab, int vec_ok, const int64_t* __restrict__ row_off,
                          const int64_t* __restrict__ col_off) {
@@ -1614,7 +1614,7 @@ extern "C" int ndmps_gram_indexed_f32(const float* d_base, int64_t m, int64_t n,
 // Batched Gram of `batch` matrices of one shape (n >= 128, m >= 256): h_A[b] (host array of device pointers) ->
 // d_G + b stride_G.  One launch for the whole batch (what a lockstep group of volumes needs at a site).
 namespace {
-// 64 <= n < 128: 64 x 64 tiles (gram_wide_body<64>), slabs sized for ~8 workgroups per CU over the whole group
+// 64 <= n < 128: 64 x 64 tiles (gram_wide_body<64>), slabs sized for ~10 workgroups per CU over the whole group (two rounds at five resident)
 inline bool gram_use_wide_batched(int batch, int64_t m, int64_t n) { return batch >= 2 && n >= 64 && n < 128 && m >= 256; }
 struct GramWideBatchGeom {
   int tiles_1d, n_tiles, n_slabs;
@@ -1624,7 +1624,7 @@ GramWideBatchGeom gram_wide_batched_geometry(int batch, int64_t m, int64_t n) {
   GramWideBatchGeom g;
   g.tiles_1d = (int)ndmps::ceil_div(n, 64);
   g.n_tiles = g.tiles_1d * (g.tiles_1d + 1) / 2;
-  const int64_t want = std::max<int64_t>(1, ndmps::ceil_div((int64_t)8 * ndmps::kNumCU, (int64_t)batch * g.n_tiles));
+  const int64_t want = std::max<int64_t>(1, ndmps::ceil_div((int64_t)10 * ndmps::kNumCU, (int64_t)batch * g.n_tiles));
   g.rows_per_slab = ndmps::round_up(std::max<int64_t>(ndmps::ceil_div(m, want), 4 * GW_KB), GW_KB);
   g.n_slabs = (int)std::max<int64_t>(1, ndmps::ceil_div(m, g.rows_per_slab));
   return g;
