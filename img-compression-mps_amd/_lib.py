@@ -107,6 +107,7 @@ SIGNATURES = {
     "ndmps_syevd_topk_team_fallbacks": (i64, []),
     "ndmps_syevd_topk_note_team_fallback": (C.c_int, []),
     "ndmps_debug_inject_team_abort": (C.c_int, [C.c_int]),
+    "ndmps_debug_lane_sums_f64": (C.c_int, [vp, vp, vp]),
     "ndmps_tt_sweep_pads_cores": (C.c_int, [C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_workspace_bytes": (i64, [C.c_int, C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "common.h"
+#include "lanes.h"
 
 namespace {
 
@@ -85,6 +86,8 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   double* band;        // [B][n_max][2 kBandMax] band matrix, [column][distance below the diagonal]
   double* qlog;        // [B][q_stride] reflectors of the bulge chase, [sweep][step][BW]
   int64_t q_stride;
+  int tail_lower;      // the resident part left only the stored half of the trailing block (trd_sym_kernel)
+  double* yrow;        // [B][2][8][lda] half-storage team kernel: row sums per workgroup, by parity of the column
   long long* stamps;   // [B][16] wall-clock (100 MHz) marks of the single-workgroup kernels' phases (tools/trd_probe.py)
   int n_max, lda, kp;
 };
@@ -104,11 +107,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return y;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// sum over the wave, in every lane (DPP and permlane swaps: lanes.h)
+__device__ __forceinline__ double wave_sum(double v) { return ndmps_lanes::sum_adjacent<64>(v); }
 
 // sum over the workgroup, identical in every thread; `red` holds one double per wave; NW waves
 template <int NW>
@@ -331,11 +331,8 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
     }
   }
   // ---- epilogue: rows -> one value per column, fixed order
-#pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-    acc0 += __shfl_xor(acc0, off, 64);
-    acc1 += __shfl_xor(acc1, off, 64);
-  }
+  acc0 = ndmps_lanes::sum_strided<LPR>(acc0);
+  acc1 = ndmps_lanes::sum_strided<LPR>(acc1);
   if (q == 0) {
     part[wave][2 * p] = acc0;
     part[wave][2 * p + 1] = acc1;
@@ -636,9 +633,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
       }
     }
 #pragma unroll
-    for (int off = 1; off < RPW; off <<= 1)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+    for (int k = 0; k < 4; ++k) acc[k] = ndmps_lanes::sum_adjacent<RPW>(acc[k]);
     if (q == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) part[wave][4 * p + k] = acc[k];
@@ -784,7 +779,10 @@ __global__ void __launch_bounds__(512) trd_tail_kernel(const TrdDesc* __restrict
   __syncthreads();
   for (int e = tid; e < m * m; e += 512) {
     const int r = e / m, c = e % m;
-    S[r * kTailLd + c] = A[(int64_t)(J + r) * lda + J + c] - (cv[r].vp * cv[c].wp + cv[r].wp * cv[c].vp);
+    const int gr = J + r, gc = J + c;
+    const bool mirror = w.tail_lower && (gr >> 5) < (gc >> 5);  // half storage (trd_sym_kernel): blocks above the diagonal are not stored
+    const double av = mirror ? A[(int64_t)gc * lda + gr] : A[(int64_t)gr * lda + gc];
+    S[r * kTailLd + c] = av - (cv[r].vp * cv[c].wp + cv[r].wp * cv[c].vp);
   }
   __syncthreads();
   if (tid < kTail) {  // the update is applied: nothing pending; columns >= m never contribute
@@ -847,8 +845,7 @@ __global__ void __launch_bounds__(512) trd_tail_kernel(const TrdDesc* __restrict
         *reinterpret_cast<double2*>(row + c) = sv;
       }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
+    acc = ndmps_lanes::sum_adjacent<4>(acc);
     const double vjr = r < kTail ? cv[r].vj : 0.0;
     double dot = (t == 0 && r < m && r > jj) ? acc * vjr : 0.0;
     dot = wave_sum(dot);
@@ -1745,9 +1742,7 @@ __global__ void __launch_bounds__(256) trd_back_kernel(const TrdDesc* __restrict
         y[WYB - 1 - q] = s;
       }
 #pragma unroll
-      for (int off = SEG / 2; off > 0; off >>= 1)
-#pragma unroll
-        for (int a = 0; a < WYB; ++a) y[a] += __shfl_xor(y[a], off, 64);
+      for (int a = 0; a < WYB; ++a) y[a] = ndmps_lanes::sum_adjacent<SEG>(y[a]);
       const double* T = tls[t & 1][gq];
       double z[WYB];
 #pragma unroll
@@ -1871,6 +1866,7 @@ __global__ void trd_clear_status_kernel(TrdDesc* __restrict__ desc, int batch, T
 }
 
 #include "eig_band.inc"
+#include "eig_sym.inc"
 
 // Test hook (ndmps_debug_inject_team_abort): what an aborted team launch leaves behind, without the 3 s wait
 __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
@@ -1881,7 +1877,7 @@ __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
 // ------------------------------------------------------------------------------------------ host side
 struct TrdLayout {
   int64_t n_max, lda, kp;
-  int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, total;
+  int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -1921,6 +1917,7 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_band = take(band_ok ? batch * n_max * 2 * kBandMax * 8 : 0);
   l.q_stride = band_ok ? n_max * (n_max + 2 * kBandMax) : 0;
   l.off_qlog = take(batch * l.q_stride * 8);
+  l.off_yrow = take(band_ok ? batch * 2 * 8 * l.lda * 8 : 0);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -1951,6 +1948,8 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.band = (double*)(base + l.off_band);
   w.qlog = (double*)(base + l.off_qlog);
   w.q_stride = l.q_stride;
+  w.yrow = (double*)(base + l.off_yrow);
+  w.tail_lower = 0;
   w.n_max = (int)l.n_max;
   w.lda = (int)l.lda;
   w.kp = (int)l.kp;
@@ -1966,6 +1965,7 @@ thread_local int g_team_off = 0;
 std::atomic<long long> g_team_fallbacks{0};
 std::atomic<int> g_inject_abort{0};
 
+constexpr bool kSymDefault = false;  // half-storage team kernel for nine matrices and more when NDMPS_TRD_SYM is not set
 constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction when NDMPS_TRD_BAND is not set (0: off)
 
 // kernels that need more than 64 KB of dynamic LDS are opted in once per device
@@ -2050,8 +2050,9 @@ int trd_check_sizes(int batch, const int64_t* h_n, int64_t& n_max) {
 
 // Tridiagonalisation of every matrix named by the descriptors (resident launch for orders <= 512 unless switched
 // off, column launches otherwise), the last kTail columns in LDS, then the min(k_max, n) largest eigenvalues.
-int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t k_max, const TrdLayout& l, const TrdWork& w,
+int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t k_max, const TrdLayout& l, const TrdWork& w_in,
                           TrdDesc* desc, hipStream_t s) {
+  TrdWork w = w_in;  // tail_lower is decided here
   const unsigned B = (unsigned)batch;
   const int load_grid = (int)std::min<int64_t>(ndmps::ceil_div(n_max * l.lda, 256), 512);
   hipLaunchKernelGGL(trd_load_kernel, dim3(load_grid, B), dim3(256), 0, s, desc, w);
@@ -2117,7 +2118,13 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
     NDMPS_TRY(team_slots(slots));
     // one to four matrices: 8-column blocks (64 workgroups per order-512 matrix, one per CU)
     const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= slots && !getenv("NDMPS_TRD_TEAM_WIDE");
-    const int team_size = (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
+    // nine matrices and more: half storage (eig_sym.inc), 8 workgroups per order-512 matrix -- a group of 32 takes one
+    // workgroup slot per CU and shares the GPU with the other group's reduction or kernels
+    const char* sym_env = getenv("NDMPS_TRD_SYM");
+    const bool sym = !narrow_team && n_max <= 512 && (sym_env ? atoi(sym_env) != 0 : kSymDefault) &&
+                     (int64_t)batch * ndmps::ceil_div(n_max, 32) > slots / 2;
+    w.tail_lower = sym ? 1 : 0;
+    const int team_size = sym ? (int)ndmps::ceil_div(ndmps::ceil_div(n_max, 32), 2) : (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
     const int per_launch = std::max(1, slots / team_size);
     int inject = g_inject_abort.load();
     while (inject > 0 && !g_inject_abort.compare_exchange_weak(inject, inject - 1)) {
@@ -2136,7 +2143,8 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
       for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const unsigned epoch = epoch_counter.fetch_add(1);
         const dim3 grid((unsigned)team_size, (unsigned)std::min(per_launch, batch - b0));
-        if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, w, b0, epoch);
+        if (sym) hipLaunchKernelGGL(trd_sym_kernel, grid, dim3(256), 0, s, desc, w, b0);
+        else if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, w, b0, epoch);
         else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, w, b0, epoch);
         else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, w, b0, epoch);
       }
@@ -2379,6 +2387,35 @@ extern "C" int ndmps_syevd_topk_note_team_fallback(void) {  // for callers that 
 }
 // Test hook: the next `launches` resident launches are replaced by what an aborted one leaves behind (status 2 in
 // every descriptor, the reduction not done), without the 3 s wait.
+namespace {
+__global__ void lane_sums_kernel(const double* __restrict__ in, double* __restrict__ out) {
+  const int l = threadIdx.x;
+  const double v = in[l];
+  using namespace ndmps_lanes;
+  out[0 * 64 + l] = sum_adjacent<2>(v);
+  out[1 * 64 + l] = sum_adjacent<4>(v);
+  out[2 * 64 + l] = sum_adjacent<8>(v);
+  out[3 * 64 + l] = sum_adjacent<16>(v);
+  out[4 * 64 + l] = sum_adjacent<32>(v);
+  out[5 * 64 + l] = sum_adjacent<64>(v);
+  out[6 * 64 + l] = sum_strided<1>(v);
+  out[7 * 64 + l] = sum_strided<2>(v);
+  out[8 * 64 + l] = sum_strided<4>(v);
+  out[9 * 64 + l] = sum_strided<8>(v);
+  out[10 * 64 + l] = sum_strided<16>(v);
+  out[11 * 64 + l] = sum_strided<32>(v);
+}
+}  // namespace
+
+// TEST HOOK: the cross-lane sums of lanes.h on one wave: out[12][64] = sums over 2, 4, ..., 64 adjacent lanes, then over
+// the lanes with equal lane % 1, 2, ..., 32, of in[64]
+extern "C" int ndmps_debug_lane_sums_f64(const double* d_in, double* d_out, void* stream) {
+  if (!d_in || !d_out) return NDMPS_EINVAL;
+  hipLaunchKernelGGL(lane_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_in, d_out);
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
 extern "C" int ndmps_debug_inject_team_abort(int launches) {
   g_inject_abort.store(launches > 0 ? launches : 0);
   return NDMPS_OK;

@@ -266,6 +266,10 @@ int ndmps_syevd_topk_set_team(int enabled);
 int64_t ndmps_syevd_topk_team_fallbacks(void);
 int ndmps_syevd_topk_note_team_fallback(void);
 int ndmps_debug_inject_team_abort(int launches);
+/* TEST HOOK: the cross-lane sums the tridiagonalisation kernels fold with (csrc/lanes.h: DPP moves and permlane swaps in
+ * place of ds_bpermute), on one wave: d_out[12][64] = the sums of d_in[64] over 2, 4, 8, 16, 32, 64 adjacent lanes, then
+ * over the lanes with equal lane % 1, 2, 4, 8, 16, 32 -- every lane holds its group's sum. */
+int ndmps_debug_lane_sums_f64(const double* d_in, double* d_out, ndmps_stream_t stream);
 /* Phase 2 with the rank decided ON THE DEVICE from phase 1's eigenvalues: k_b = #{i < k_cap : sqrt(w_i) > cutoff
  * sqrt(w_0)}, at least 1.  Columns k_b .. k_cap-1 of V are zero-filled, so a caller sizes everything by k_cap and
  * never waits for the rank.  d_ranks[b] (device) receives k_b, d_spectra (may be NULL) the k_cap leading singular

@@ -182,3 +182,59 @@ def test_two_stage_reduction_gives_lapacks_eigenpairs(lib, bw, monkeypatch):
         vk = vv[b, : n * n].reshape(n, n)[:, :k]
         assert np.abs(vk.T @ vk - np.eye(k)).max() < 1e-12
         assert np.abs(m @ vk - vk * wv[b, :k]).max() < 1e-12 * ref[0]
+
+
+def test_cross_lane_sums_of_the_tridiagonalisation_kernels(lib):
+    """csrc/lanes.h (DPP moves inside a row of 16 lanes, permlane swaps between rows) against plain sums: every
+    lane must hold the sum of its group -- 2 ... 64 adjacent lanes, and the lanes with equal lane % 1 ... 32."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(64) * np.logspace(0, 3, 64)
+    d_in = torch.from_numpy(x).to(DEV)
+    d_out = torch.zeros((12, 64), dtype=torch.float64, device=DEV)
+    _lib.check(lib.ndmps_debug_lane_sums_f64(d_in.data_ptr(), d_out.data_ptr(), _lib.stream_ptr()))
+    out = d_out.cpu().numpy()
+    scale = np.abs(x).sum()
+    lanes = np.arange(64)
+    for row, n in enumerate([2, 4, 8, 16, 32, 64]):
+        want = x.reshape(-1, n).sum(axis=1)[lanes // n]
+        assert np.abs(out[row] - want).max() < 1e-15 * scale, f"{n} adjacent lanes"
+    for row, stride in enumerate([1, 2, 4, 8, 16, 32], start=6):
+        want = x.reshape(-1, stride).sum(axis=0)[lanes % stride]
+        assert np.abs(out[row] - want).max() < 1e-15 * scale, f"lanes with equal lane % {stride}"
+
+
+def test_half_storage_reduction_gives_lapacks_eigenpairs(lib, monkeypatch):
+    """The resident tridiagonalisation on half the matrix (csrc/eig_sym.inc; batches that fill more than half the
+    GPU's workgroup slots) against LAPACK: mixed orders in one launch -- full 16 block-columns, a ragged last block,
+    an odd number of block-columns (the middle workgroup holds one), orders the tail kernel reduces alone."""
+    monkeypatch.setenv("NDMPS_TRD_SYM", "1")
+    rng = np.random.default_rng(17)
+    orders = [512] * 6 + [500] * 4 + [480, 449, 384, 320, 257, 200, 137, 129, 96, 33]
+    n_max, k = max(orders), 24
+    mats = []
+    for n in orders:
+        x = rng.standard_normal((2 * n, n)) * np.logspace(0, -5, n)
+        mats.append(x.T @ x)
+    flat = torch.zeros((len(orders), n_max * n_max), dtype=torch.float64, device=DEV)
+    for b, (n, m) in enumerate(zip(orders, mats)):
+        flat[b, : n * n] = torch.from_numpy(m.reshape(-1)).to(DEV)
+    v = torch.zeros_like(flat)
+    w = torch.zeros((len(orders), n_max), dtype=torch.float64, device=DEV)
+    nbytes = int(lib.ndmps_syevd_topk_workspace_bytes(n_max, len(orders), k))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    sizes = _lib.i64_array(orders)
+    for _ in range(2):  # twice on one workspace: nothing of the first run may leak into the second
+        _lib.check(lib.ndmps_syevd_topk_values_f64(len(orders), flat.data_ptr(), n_max * n_max, sizes, v.data_ptr(),
+                                                   n_max * n_max, w.data_ptr(), n_max, k, ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        status = (C.c_int * len(orders))()
+        _lib.check(lib.ndmps_syevd_topk_vectors_f64(len(orders), sizes, _lib.i64_array([min(k, n) for n in orders]), k,
+                                                    ws.data_ptr(), nbytes, status, _lib.stream_ptr()))
+        assert list(status) == [0] * len(orders)
+        wv, vv = w.cpu().numpy(), v.cpu().numpy()
+        for b, (n, m) in enumerate(zip(orders, mats)):
+            kb = min(k, n)
+            ref = np.linalg.eigvalsh(m)[::-1]
+            assert np.allclose(wv[b, :kb], ref[:kb], rtol=0, atol=2e-14 * ref[0]), n
+            vk = vv[b, : n * n].reshape(n, n)[:, :kb]
+            assert np.abs(vk.T @ vk - np.eye(kb)).max() < 1e-12, n
+            assert np.abs(m @ vk - vk * wv[b, :kb]).max() < 1e-12 * ref[0], n
