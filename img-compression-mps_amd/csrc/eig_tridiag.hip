@@ -87,6 +87,7 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   double* qlog;        // [B][q_stride] reflectors of the bulge chase, [sweep][step][BW]
   int64_t q_stride;
   int tail_lower;      // the resident part left only the stored half of the trailing block (trd_sym_kernel)
+  int xcd_team, xcd_count;  // resident launches as a 1-D grid placed team by team on the XCDs (team_place); 0: 2-D grid
   double* yrow;        // [B][2][8][lda] half-storage team kernel: row sums per workgroup, by parity of the column
   long long* stamps;   // [B][16] wall-clock (100 MHz) marks of the single-workgroup kernels' phases (tools/trd_probe.py)
   int n_max, lda, kp;
@@ -415,6 +416,28 @@ __device__ __forceinline__ unsigned long long team_poll(const unsigned long long
 // and a consumer's use, instead of store acknowledgement + counter update + counter poll + data load.  The records
 // of a matrix are double-buffered by the parity of the column like the plain vectors: nobody can be two columns
 // ahead of anybody, because publishing column j + 2 needs everybody's column j + 1.
+// Workgroups go to the 8 XCDs round robin in dispatch order (workgroup L runs on XCD L % 8; each XCD has its own L2).
+// A 1-D grid of team_size x count workgroups is dealt so that the members of a team share an XCD: their exchange --
+// a handful of 4 KB vectors and one counter per column -- then stays in that XCD's L2.  Nothing depends on the
+// placement for correctness (the exchange is agent-scope either way).  The last count % 8 teams are dealt as they come.
+__device__ __forceinline__ void team_place(const TrdWork& w, int& member, int& team) {
+  if (w.xcd_count <= 0) {
+    member = blockIdx.x;
+    team = blockIdx.y;
+    return;
+  }
+  const int L = blockIdx.x, full = w.xcd_count & ~7;
+  if (L < full * w.xcd_team) {
+    const int t = L >> 3;
+    member = t % w.xcd_team;
+    team = (t / w.xcd_team) * 8 + (L & 7);
+  } else {
+    const int r = w.xcd_count - full, l2 = L - full * w.xcd_team;
+    member = l2 / r;
+    team = full + l2 % r;
+  }
+}
+
 // CW: columns per workgroup, 32 (16 workgroups per order-512 matrix) or 8 (64 of them, for one to four matrices:
 // the tile loop is a quarter as long, the per-column arithmetic of the slowest member shrinks with it).
 template <int NR, bool TAGGED, int CW = 32>
@@ -424,16 +447,18 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
   constexpr int RPW = 64 / LPR;      // rows per wave instruction
   constexpr int RPI = 4 * RPW;       // rows per tile of the workgroup
   constexpr int NT = 512 / RPI;      // tiles per lane: 512 rows
-  TrdDesc& d = desc[b0 + blockIdx.y];
+  int member, team;
+  team_place(w, member, team);
+  TrdDesc& d = desc[b0 + team];
   const int n = d.n;
   const int J = n - kTail;           // columns 0 .. J - 1 are reduced here, the rest by the tail kernel
-  const int c0 = blockIdx.x * CW;
+  const int c0 = member * CW;
   if (J <= 0 || c0 >= n) return;
   const int nblk = (n + CW - 1) / CW;
   const int j_last = min(J - 1, c0 + CW - 2);  // the block's columns are finished once j + 1 >= c0 + CW
   const int lda = w.lda;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t b = b0 + blockIdx.y;
+  const int64_t b = b0 + team;
   double* A = w.A + b * w.n_max * lda;
   double* Vh = w.Vh + b * w.n_max * lda;
   double* ybuf = w.y + b * 2 * lda;
@@ -585,7 +610,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     const double alpha = r_j1 - ((taup * y_j1 - al * v_j1) + wpj * v_j1);
     double beta, tau, scale;
     householder(alpha, sigma, beta, tau, scale);
-    const bool writer = (int)blockIdx.x == (j + 1) / CW;
+    const bool writer = member == (j + 1) / CW;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int i = tid + 256 * r;
@@ -646,7 +671,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     }
     if (j + 1 >= J) break;  // the tail kernel continues from the stored matrix
     // ---- column j + 1 of the updated matrix, by its owner
-    if ((int)blockIdx.x == (j + 1) / CW) {
+    if (member == (j + 1) / CW) {
       const int kk = j + 1 - c0;
       if (p == kk / 4) {
         double* out = xc + ((j + 1) & 1) * lda;
@@ -1950,6 +1975,7 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.q_stride = l.q_stride;
   w.yrow = (double*)(base + l.off_yrow);
   w.tail_lower = 0;
+  w.xcd_team = w.xcd_count = 0;
   w.n_max = (int)l.n_max;
   w.lda = (int)l.lda;
   w.kp = (int)l.kp;
@@ -1965,6 +1991,7 @@ thread_local int g_team_off = 0;
 std::atomic<long long> g_team_fallbacks{0};
 std::atomic<int> g_inject_abort{0};
 
+constexpr bool kTeamXcdDefault = true;   // teams placed XCD by XCD (team_place) when NDMPS_TRD_XCD is not set
 constexpr bool kSymDefault = false;  // half-storage team kernel for nine matrices and more when NDMPS_TRD_SYM is not set
 constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction when NDMPS_TRD_BAND is not set (0: off)
 
@@ -2126,6 +2153,8 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
     w.tail_lower = sym ? 1 : 0;
     const int team_size = sym ? (int)ndmps::ceil_div(ndmps::ceil_div(n_max, 32), 2) : (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
     const int per_launch = std::max(1, slots / team_size);
+    const char* xcd_env = getenv("NDMPS_TRD_XCD");
+    const bool xcd_placed = xcd_env ? atoi(xcd_env) != 0 : kTeamXcdDefault;
     int inject = g_inject_abort.load();
     while (inject > 0 && !g_inject_abort.compare_exchange_weak(inject, inject - 1)) {
     }
@@ -2142,11 +2171,18 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
                                                             : (int64_t)std::min(per_launch, batch) * team_size <= slots / 2;
       for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const unsigned epoch = epoch_counter.fetch_add(1);
-        const dim3 grid((unsigned)team_size, (unsigned)std::min(per_launch, batch - b0));
-        if (sym) hipLaunchKernelGGL(trd_sym_kernel, grid, dim3(256), 0, s, desc, w, b0);
-        else if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, w, b0, epoch);
-        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, w, b0, epoch);
-        else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, w, b0, epoch);
+        const int count = std::min(per_launch, batch - b0);
+        TrdWork wl = w;
+        dim3 grid((unsigned)team_size, (unsigned)count);
+        if (xcd_placed) {
+          wl.xcd_team = team_size;
+          wl.xcd_count = count;
+          grid = dim3((unsigned)(team_size * count));
+        }
+        if (sym) hipLaunchKernelGGL(trd_sym_kernel, grid, dim3(256), 0, s, desc, wl, b0);
+        else if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
+        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
+        else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
       }
     }, narrow_team || (int64_t)std::min(per_launch, batch) * team_size <= slots / 2));
     // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
