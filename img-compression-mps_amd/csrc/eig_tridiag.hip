@@ -88,6 +88,7 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   int64_t q_stride;
   int tail_lower;      // the resident part left only the stored half of the trailing block (trd_sym_kernel)
   int xcd_team, xcd_count;  // resident launches as a 1-D grid placed team by team on the XCDs (team_place); 0: 2-D grid
+  int xcd_pair;        // second workgroup of a CU: members in reverse order (early leavers beside late ones)
   double* yrow;        // [B][2][8][lda] half-storage team kernel: row sums per workgroup, by parity of the column
   long long* stamps;   // [B][16] wall-clock (100 MHz) marks of the single-workgroup kernels' phases (tools/trd_probe.py)
   int n_max, lda, kp;
@@ -420,22 +421,27 @@ __device__ __forceinline__ unsigned long long team_poll(const unsigned long long
 // A 1-D grid of team_size x count workgroups is dealt so that the members of a team share an XCD: their exchange --
 // a handful of 4 KB vectors and one counter per column -- then stays in that XCD's L2.  Nothing depends on the
 // placement for correctness (the exchange is agent-scope either way).  The last count % 8 teams are dealt as they come.
-__device__ __forceinline__ void team_place(const TrdWork& w, int& member, int& team) {
+__device__ __forceinline__ bool team_place(const TrdWork& w, int& member, int& team) {
   if (w.xcd_count <= 0) {
     member = blockIdx.x;
     team = blockIdx.y;
-    return;
+    return true;
   }
   const int L = blockIdx.x, full = w.xcd_count & ~7;
   if (L < full * w.xcd_team) {
     const int t = L >> 3;
     member = t % w.xcd_team;
     team = (t / w.xcd_team) * 8 + (L & 7);
+    if (w.xcd_pair && ((t >> 5) & 1)) {  // 32 CUs per XCD: workgroup t + 32 joins t's CU, with the members in reverse order
+      const int blk = min(w.xcd_team, 32), pos = member % blk;  // (xcd_pair only if 32 % team == 0 or team % 32 == 0)
+      member += blk - 1 - 2 * pos;
+    }
   } else {
     const int r = w.xcd_count - full, l2 = L - full * w.xcd_team;
     member = l2 / r;
     team = full + l2 % r;
   }
+  return true;
 }
 
 // CW: columns per workgroup, 32 (16 workgroups per order-512 matrix) or 8 (64 of them, for one to four matrices:
@@ -448,7 +454,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
   constexpr int RPI = 4 * RPW;       // rows per tile of the workgroup
   constexpr int NT = 512 / RPI;      // tiles per lane: 512 rows
   int member, team;
-  team_place(w, member, team);
+  if (!team_place(w, member, team)) return;
   TrdDesc& d = desc[b0 + team];
   const int n = d.n;
   const int J = n - kTail;           // columns 0 .. J - 1 are reduced here, the rest by the tail kernel
@@ -1975,7 +1981,7 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.q_stride = l.q_stride;
   w.yrow = (double*)(base + l.off_yrow);
   w.tail_lower = 0;
-  w.xcd_team = w.xcd_count = 0;
+  w.xcd_team = w.xcd_count = w.xcd_pair = 0;
   w.n_max = (int)l.n_max;
   w.lda = (int)l.lda;
   w.kp = (int)l.kp;
@@ -2177,6 +2183,9 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
         if (xcd_placed) {
           wl.xcd_team = team_size;
           wl.xcd_count = count;
+          // early leavers (low block-columns) beside late ones: needs whole teams on either side of every 32nd workgroup
+          const bool pairable = 32 % team_size == 0 || team_size % 32 == 0;
+          wl.xcd_pair = sym || !pairable ? 0 : getenv("NDMPS_TRD_PAIR") ? atoi(getenv("NDMPS_TRD_PAIR")) : 1;
           grid = dim3((unsigned)(team_size * count));
         }
         if (sym) hipLaunchKernelGGL(trd_sym_kernel, grid, dim3(256), 0, s, desc, wl, b0);
