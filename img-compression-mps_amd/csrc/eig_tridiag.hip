@@ -23,6 +23,7 @@
 // fits the LDS (<= 128 x 128) one workgroup per matrix finishes the reduction without further launches.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -901,6 +902,213 @@ __global__ void __launch_bounds__(512) trd_tail_kernel(const TrdDesc* __restrict
     tt[n - 1] = 0.0;
   }
   for (int i = tid; i < lda; i += 512) Vh[(int64_t)(n - 1) * lda + i] = 0.0;
+}
+
+// The same tail with the trailing matrix in REGISTERS: thread (rg, cg) = (tid / 16, tid % 16) owns the rows rg + 32 a
+// (a < 4) and the columns cg + 16 q (q < 8): for a fixed slot the 16 lanes of a row group read 16 consecutive column
+// records (no bank conflicts), and the row sums fold over those 16 adjacent lanes by DPP.  The LDS version reads, per
+// column and thread, 32 column records and its 32 matrix elements back and forth (1.5 KB); here a thread reads 4 row
+// records and 8 column records and the matrix stays put.  Blocks of 32 rows / 16 columns that lie at or before the
+// current column are skipped (uniform branches).  Row jj + 1 -- needed in full by the next column's prologue -- is
+// exported to LDS by its owners in the pass that brings it up to date.
+__global__ void __launch_bounds__(512) trd_tail_reg_kernel(const TrdDesc* __restrict__ desc, TrdWork w) {
+  const TrdDesc& d = desc[blockIdx.y];
+  const int n = d.n;
+  const int J = max(n - kTail, 0), m = n - J;
+  const int lda = w.lda;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.y;
+  const double* A = w.A + b * w.n_max * lda;
+  double* Vh = w.Vh + b * w.n_max * lda;
+  const double* ybuf = w.y + b * 2 * lda;
+  double* dd = w.d + b * w.n_max;
+  double* ee = w.e + b * w.n_max;
+  double* tt = w.tau + b * w.n_max;
+  __shared__ RowVec cv[kTail];      // {v', w', v_j} per row / column of the trailing matrix
+  __shared__ double xrow[kTail];    // row jj of the matrix, current through step jj - 2
+  __shared__ double yv[kTail];      // y = S v_j of the pass, for the prologue wave
+  __shared__ double red_s[8];
+
+  // the reflectors of the tail are zero outside rows J .. n - 1: written once, the loop stores the live part only
+  for (int64_t e = tid; e < (int64_t)m * lda; e += 512) {
+    const int i = (int)(e % lda);
+    if (i < J || i >= n) Vh[(int64_t)J * lda + e] = 0.0;
+  }
+  // pending update of the last column of the resident part
+  if (J >= 1) {
+    const double* yprev = ybuf + ((J - 1) & 1) * lda;
+    const double* vprev = Vh + (int64_t)(J - 1) * lda;
+    const double taup = tt[J - 1];
+    double dot = 0.0, vv = 0.0, y0 = 0.0;
+    if (tid < m) {
+      vv = vprev[J + tid];
+      y0 = yprev[J + tid];
+      dot = y0 * vv;
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) red_s[wave] = dot;
+    __syncthreads();
+    dot = 0.0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) dot += red_s[x];
+    const double al = 0.5 * taup * taup * dot;
+    if (tid < kTail) {
+      cv[tid].vp = tid < m ? vv : 0.0;
+      cv[tid].wp = tid < m ? taup * y0 - al * vv : 0.0;
+    }
+  } else if (tid < kTail) {
+    cv[tid].vp = 0.0;
+    cv[tid].wp = 0.0;
+  }
+  __syncthreads();
+  const int rg = tid >> 4, cg = tid & 15;
+  double s[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = rg + 32 * a, gr = J + r;
+    const double vpr = cv[r].vp, wpr = cv[r].wp;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = cg + 16 * q, gc = J + c;
+      double v = 0.0;
+      if (r < m && c < m) {
+        const bool mirror = w.tail_lower && (gr >> 5) < (gc >> 5);  // half storage: blocks above the diagonal are not stored
+        const double av = mirror ? A[(int64_t)gc * lda + gr] : A[(int64_t)gr * lda + gc];
+        v = av - (vpr * cv[c].wp + wpr * cv[c].vp);
+      }
+      s[a][q] = v;
+    }
+  }
+  if (rg == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xrow[cg + 16 * q] = s[0][q];
+  }
+  __syncthreads();
+  if (tid < kTail) {  // the update is applied: nothing pending
+    cv[tid].vp = 0.0;
+    cv[tid].wp = 0.0;
+    cv[tid].vj = 0.0;
+  }
+  __syncthreads();
+
+  // Wave 0 is the PROLOGUE wave: lane l keeps the entries l and l + 64 of the pending update (v', w') in registers and
+  // does, between the passes over the matrix, everything that is O(m): w of the finished step, the next row with the
+  // update applied, sigma, the Householder scalars, the reflector -- two wave-wide sums by DPP, no barrier in
+  // between.  Two barriers per column (the LDS version: four, with two block reductions through LDS).
+  const int i0 = lane, i1 = lane + 64;
+  double pv0 = 0.0, pv1 = 0.0, pw0 = 0.0, pw1 = 0.0;  // pending v', w' at i0, i1 (wave 0)
+  double tau_now = 0.0;                                // tau of the step whose pass is running (wave 0)
+  auto pick = [&](double lo, double hi, int idx) {    // entry idx of a vector held as (lane, lane + 64): idx is uniform
+    const double src = idx < 64 ? lo : hi;
+    const long long bits = __double_as_longlong(src);
+    const int l = __builtin_amdgcn_readlane((int)bits, idx & 63), h = __builtin_amdgcn_readlane((int)(bits >> 32), idx & 63);
+    return __longlong_as_double(((long long)h << 32) | (unsigned)l);
+  };
+  for (int jj = 0; jj + 1 < m; ++jj) {
+    const int j = J + jj;
+    if (wave == 0) {
+      // ---- row jj with the pending update -> x, sigma, alpha, d_j; reflector
+      const double vpj = pick(pv0, pv1, jj), wpj = pick(pw0, pw1, jj);
+      double x0 = 0.0, x1 = 0.0;
+      if (i0 < m) x0 = xrow[i0] - (vpj * pw0 + wpj * pv0);
+      if (i1 < m) x1 = xrow[i1] - (vpj * pw1 + wpj * pv1);
+      double sigma = (i0 > jj + 1 ? x0 * x0 : 0.0) + (i1 > jj + 1 ? x1 * x1 : 0.0);
+      sigma = wave_sum(sigma);
+      const double alpha = pick(x0, x1, jj + 1), djj = pick(x0, x1, jj);
+      double beta, tau, scale;
+      householder(alpha, sigma, beta, tau, scale);
+      const double v0 = i0 > jj + 1 ? x0 * scale : (i0 == jj + 1 ? 1.0 : 0.0);
+      const double v1 = i1 > jj + 1 ? x1 * scale : (i1 == jj + 1 ? 1.0 : 0.0);
+      if (i0 < m) {
+        cv[i0].vj = v0;
+        Vh[(int64_t)j * lda + J + i0] = v0;
+      }
+      if (i1 < m) {
+        cv[i1].vj = v1;
+        Vh[(int64_t)j * lda + J + i1] = v1;
+      }
+      if (lane == 0) {
+        dd[j] = djj;
+        ee[j] = beta;
+        tt[j] = tau;
+      }
+      tau_now = tau;
+      pv0 = v0;  // v' of the step that is pending from now on; w' follows behind the pass
+      pv1 = v1;
+    }
+    __syncthreads();
+    // ---- one pass over the registers: pending update (step jj - 1), y = S v_j, row jj + 1 exported
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+      const int q0 = (jj + 1) >> 4, a0 = (jj + 1) >> 5;  // first column / row block with an index beyond jj
+      double vpr[4], wpr[4];
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        vpr[a4] = cv[rg + 32 * a4].vp;
+        wpr[a4] = cv[rg + 32 * a4].wp;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // four column records at a time: the kernel stays within 128 registers
+        double vpc[4], wpc[4], vjc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const RowVec cr = cv[cg + 16 * (4 * h + q)];
+          vpc[q] = cr.vp;
+          wpc[q] = cr.wp;
+          vjc[q] = cr.vj;
+        }
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) {
+          if (a4 >= a0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (4 * h + q >= q0) {
+                s[a4][4 * h + q] = fma(-vpr[a4], wpc[q], fma(-wpr[a4], vpc[q], s[a4][4 * h + q]));
+                acc[a4] = fma(s[a4][4 * h + q], vjc[q], acc[a4]);
+              }
+            }
+          }
+        }
+      }
+      if (rg == ((jj + 1) & 31)) {  // one unrolled copy per row slot: no run-time register index
+#define NDMPS_TAIL_PUT(AX) _Pragma("unroll") for (int q = 0; q < 8; ++q) xrow[cg + 16 * q] = s[AX][q];
+        switch ((jj + 1) >> 5) {
+          case 0: NDMPS_TAIL_PUT(0) break;
+          case 1: NDMPS_TAIL_PUT(1) break;
+          case 2: NDMPS_TAIL_PUT(2) break;
+          default: NDMPS_TAIL_PUT(3) break;
+        }
+#undef NDMPS_TAIL_PUT
+      }
+    }
+    const double y0 = ndmps_lanes::sum_adjacent<16>(acc[0]), y1 = ndmps_lanes::sum_adjacent<16>(acc[1]);
+    const double y2 = ndmps_lanes::sum_adjacent<16>(acc[2]), y3 = ndmps_lanes::sum_adjacent<16>(acc[3]);
+    if (cg < 4) {  // lanes cg = 0 .. 3 of a row group publish rows rg + 32 cg
+      const int rr = rg + 32 * cg;
+      const double yr = (cg & 2) ? ((cg & 1) ? y3 : y2) : ((cg & 1) ? y1 : y0);
+      yv[rr] = rr > jj && rr < m ? yr : 0.0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // ---- w of this step becomes the pending update (cv.vp / cv.wp: read by everybody behind the next barrier)
+      const double tau = tau_now;
+      const double ya = yv[i0], yb = yv[i1];
+      double dot = wave_sum(fma(ya, pv0, yb * pv1));
+      const double al = 0.5 * tau * tau * dot;
+      pw0 = tau * ya - al * pv0;
+      pw1 = tau * yb - al * pv1;
+      cv[i0].vp = pv0;
+      cv[i0].wp = pw0;
+      cv[i1].vp = pv1;
+      cv[i1].wp = pw1;
+    }
+  }
+  if (tid == 0) {
+    const int jj = m - 1;
+    dd[n - 1] = xrow[jj] - 2.0 * cv[jj].vp * cv[jj].wp;
+    ee[n - 1] = 0.0;
+    tt[n - 1] = 0.0;
+  }
 }
 
 // ----------------------------------------------------------------------------------------- bisection
@@ -2206,7 +2414,12 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
     }
     ndmps::span_end(span, s, ndmps::kSpanTridiagColumns, std::max<int64_t>(n_max - kTail, 0), span_bytes);
   }
-  hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
+  // small batches (nothing else on the GPU): the tail in registers, two barriers per column; lockstep groups: the tail
+  // in LDS -- 70 registers per thread, it starts beside the resident kernel's last workgroups (158 would wait)
+  const char* tail_env = getenv("NDMPS_TRD_TAIL");
+  const bool tail_regs = tail_env ? !strcmp(tail_env, "regs") : batch < 16;
+  if (tail_regs) hipLaunchKernelGGL(trd_tail_reg_kernel, dim3(1, B), dim3(512), 0, s, desc, w);
+  else hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
   const int kk = (int)std::min(k_max, n_max);
   hipLaunchKernelGGL(trd_bisect_kernel, dim3(ndmps::ceil_div(kk, 4), B), dim3(256),
                      (size_t)ndmps::round_up(n_max, 16) * 16, s, desc, w, kk);
