@@ -646,6 +646,17 @@ constexpr int GW_KB = 32;    // rows per staged chunk
 // (GW_TS/2)^2 sub-tile = (GW_TS/32)^2 MFMA accumulators
 // four consecutive elements as fp32 (16-byte load for fp32 input, 8-byte load for bf16 input)
 __device__ __forceinline__ float4 load4_as_f32(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// read-once streams: non-temporal (the lines are not kept in the caches in front of data that is read again)
+__device__ __forceinline__ float4 load4_stream_f32(const float* p) {
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float4 load4_stream_f32(const __bf16* p) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const bf16x4 v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p));
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
 __device__ __forceinline__ float4 load4_as_f32(const __bf16* p) {
   typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
   const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
@@ -793,6 +804,143 @@ gram_wide_batched_kernel(GramBatchPtrs ptrs, int64_t m, int64_t n, int64_t lda, 
   gram_wide_body<GW_TS, TIN>(static_cast<const TIN*>(ptrs.a[blockIdx.z]), m, n, lda, out, n_tiles_1d, rows_per_slab, vec_ok,
                              row_off, col_off, blockIdx.x, blockIdx.y);
 }
+// ----------------------------------------------------------------------------------
+// n == 64 exactly (the raw Gram of a bond cap of 32: d chi = 8 x 8 columns, 64 MB per 256^3 volume): a STREAM.
+// The tile kernel above stages 32-row chunks in LDS behind two barriers and computes the full 64 x 64 tile (16 MFMAs
+// per four rows): 1.26 ms per lockstep group of 32 alone, 2.2 ms inside a step -- 1 TB/s.  Here a wave reads four rows
+// with ONE coalesced 16-byte load per lane (lane (i, k) = (lane % 16, lane / 16) takes columns 4i .. 4i + 3 of row
+// k) and that float4 IS the four MFMA operands: component a belongs to the column block {4i + a}, so
+// v_mfma_f64_16x16x4_f64(x_a, x_b) accumulates G[4i + a][4j + b] -- a column permutation that is undone when the tile is
+// written.  Ten MFMAs per four rows (blocks a <= b), no LDS, no barrier in the loop, eight loads in flight per lane
+// (offsets of a gathered operand one block further ahead).  The four waves of a workgroup take rows 4w .. 4w + 3 of
+// every 16 and add their accumulators in a fixed order at the end; the partial tile has the layout
+// tile_reduce_batched_kernel<64> expects.
+template <typename TIN, bool GATHER>
+__global__ void __launch_bounds__(256, 3)  // three waves per SIMD: one waiting for its loads leaves the MFMA pipe to two
+gram64_stream_kernel(GramBatchPtrs ptrs, int64_t m, int64_t lda, double* __restrict__ partial, int64_t rows_per_slab,
+                     const int64_t* __restrict__ row_off, const int64_t* __restrict__ col_off) {
+  constexpr int U = 8;  // k-steps (of four rows per wave) per block
+  const TIN* A = static_cast<const TIN*>(ptrs.a[blockIdx.z]);
+  double* out = partial + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kk = lane >> 4;
+  const int64_t r_begin = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r_end = min(m, r_begin + rows_per_slab);
+  const int64_t n_steps = (r_end - r_begin + 15) / 16;
+  const int64_t n_blocks = (n_steps + U - 1) / U;
+  const int64_t coff = GATHER ? col_off[4 * li] : 4 * li;
+  const int64_t row0 = r_begin + 4 * wave + kk;  // this lane's row at step 0; + 16 per step
+
+  f64x4 acc[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) acc[q] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#define NDMPS_GRAM64_STEP(v)                                                                                     \
+  {                                                                                                              \
+    const double x0 = (double)(v).x, x1 = (double)(v).y, x2 = (double)(v).z, x3 = (double)(v).w;                 \
+    NDMPS_GRAM64_MFMAS(x0, x1, x2, x3)                                                                           \
+  }
+#define NDMPS_GRAM64_MFMAS(x0, x1, x2, x3)                                                                       \
+  {                                                                                                              \
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc[0], 0, 0, 0);                                      \
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, acc[1], 0, 0, 0);                                      \
+    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x2, acc[2], 0, 0, 0);                                      \
+    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x3, acc[3], 0, 0, 0);                                      \
+    acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc[4], 0, 0, 0);                                      \
+    acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x2, acc[5], 0, 0, 0);                                      \
+    acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x3, acc[6], 0, 0, 0);                                      \
+    acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, x2, acc[7], 0, 0, 0);                                      \
+    acc[8] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, x3, acc[8], 0, 0, 0);                                      \
+    acc[9] = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, x3, acc[9], 0, 0, 0);                                      \
+  }
+  // Full blocks (every row of every step exists): straight-line loads -- a load under a branch makes the compiler
+  // wait for ALL outstanding loads (s_waitcnt vmcnt(0)) in front of the MFMAs, prefetched ones included.  Blocks
+  // fetched ahead beyond the last full one repeat it (valid addresses, never used).
+  const int64_t n_full = (r_end - r_begin) / (16 * U);
+  if (n_full > 0) {
+    // a ring of U loads per lane: step s takes slot s % U and refills it at once with step s + U (its offset -- the row's
+    // entry of the table of a gathered operand -- was fetched U steps before that): a constant distance of U steps
+    // (80 MFMAs) between a load and its use, no drain at block boundaries
+    const int64_t last = n_full * U - 1;  // steps beyond the last full one repeat it (valid addresses, never used)
+    auto offset_of = [&](int64_t step) {
+      const int64_t row = row0 + 16 * min(step, last);
+      return GATHER ? row_off[row] : row * lda;
+    };
+    float4 ring[U];
+    int64_t roff[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) roff[u] = offset_of(u);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ring[u] = load4_stream_f32(A + roff[u] + coff);
+      roff[u] = offset_of(U + u);
+    }
+    auto block = [&](int64_t blk) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // the step's operands are converted BEFORE its slot is reloaded in place, and nothing moves across steps:
+        // left to itself the scheduler hoists the block's eight loads to its top into fresh registers and copies them
+        // into the loop-carried ones -- a copy that waits for the load it follows
+        const double x0 = (double)ring[u].x, x1 = (double)ring[u].y, x2 = (double)ring[u].z, x3 = (double)ring[u].w;
+        __builtin_amdgcn_sched_barrier(0);
+        ring[u] = load4_stream_f32(A + roff[u] + coff);   // step (blk + 1) U + u
+        roff[u] = offset_of((blk + 2) * U + u);
+        NDMPS_GRAM64_MFMAS(x0, x1, x2, x3)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // four blocks per trip: at a loop header the compiler waits for EVERY outstanding load (the newest was issued ten
+    // MFMAs earlier), once per 32 steps then
+    int64_t blk = 0;
+    for (; blk + 4 <= n_full; blk += 4) {
+      block(blk);
+      block(blk + 1);
+      block(blk + 2);
+      block(blk + 3);
+    }
+    for (; blk < n_full; ++blk) block(blk);
+  }
+  // the ragged end of the slab, row by row
+  for (int64_t row = row0 + 16 * U * n_full; row < r_end + 16; row += 16) {  // uniform trip count over the wave
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < r_end) v = load4_as_f32(A + (GATHER ? row_off[row] : row * lda) + coff);
+    if (__builtin_amdgcn_ballot_w64(row < r_end) != 0) NDMPS_GRAM64_STEP(v)
+  }
+#undef NDMPS_GRAM64_STEP
+#undef NDMPS_GRAM64_MFMAS
+
+  // waves 3, 2, 1 hand their sums to wave 0 through LDS, one after the other (fixed order)
+  __shared__ double hand[10 * 256];
+#pragma unroll 1
+  for (int src = 3; src >= 1; --src) {
+    if (wave == src) {
+#pragma unroll
+      for (int q = 0; q < 10; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) hand[(q * 4 + reg) * 64 + lane] = acc[q][reg];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int q = 0; q < 10; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[q][reg] += hand[(q * 4 + reg) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    // block q = (a, b), a <= b; accumulator element (i, j) = (kk + 4 reg, li) is G[4i + a][4j + b]
+    constexpr int qa[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, qb[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = 4 * (kk + 4 * reg) + qa[q], c = 4 * li + qb[q];
+        out[r * 64 + c] = acc[q][reg];
+        if (qa[q] != qb[q]) out[c * 64 + r] = acc[q][reg];
+      }
+  }
+}
+
 // G of matrix blockIdx.z: its slabs of tile blockIdx.x summed in order; upper part mirrored; optional un-permutation
 template <int TS>
 __global__ void __launch_bounds__(256)
@@ -1619,12 +1767,15 @@ inline bool gram_use_wide_batched(int batch, int64_t m, int64_t n) { return batc
 struct GramWideBatchGeom {
   int tiles_1d, n_tiles, n_slabs;
   int64_t rows_per_slab;
+  bool stream;  // n == 64: gram64_stream_kernel (the launch also wants 16-byte groups of columns: checked there)
 };
 GramWideBatchGeom gram_wide_batched_geometry(int batch, int64_t m, int64_t n) {
   GramWideBatchGeom g;
   g.tiles_1d = (int)ndmps::ceil_div(n, 64);
   g.n_tiles = g.tiles_1d * (g.tiles_1d + 1) / 2;
-  const int64_t want = std::max<int64_t>(1, ndmps::ceil_div((int64_t)10 * ndmps::kNumCU, (int64_t)batch * g.n_tiles));
+  g.stream = n == 64 && !getenv("NDMPS_GRAM64_TILES");
+  // tiles: ~10 workgroups per CU over the group (five resident); stream: 6 per CU (three resident, long slabs)
+  const int64_t want = std::max<int64_t>(1, ndmps::ceil_div((int64_t)(g.stream ? 6 : 10) * ndmps::kNumCU, (int64_t)batch * g.n_tiles));
   g.rows_per_slab = ndmps::round_up(std::max<int64_t>(ndmps::ceil_div(m, want), 4 * GW_KB), GW_KB);
   g.n_slabs = (int)std::max<int64_t>(1, ndmps::ceil_div(m, g.rows_per_slab));
   return g;
@@ -1646,6 +1797,7 @@ int gram_wide_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, in
     if ((uintptr_t)h_A[b] % (4 * sizeof(TIN)) != 0) vec_ok = 0;
   }
   if (d_row_off) NDMPS_REQUIRE(d_col_off && vec_ok, "gathered Gram needs n %% 4 == 0 and aligned bases");
+  NDMPS_REQUIRE(!g.stream || vec_ok, "the 64-column Gram stream needs lda %% 4 == 0 and 16-byte aligned operands");
   double* partial = (double*)d_ws;
   void* span = ndmps::span_begin(s);
   for (int base = 0; base < batch; base += 64) {
@@ -1653,6 +1805,14 @@ int gram_wide_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, in
     GramBatchPtrs ptrs;
     for (int t = 0; t < count; ++t) ptrs.a[t] = h_A[base + t];
     double* part = partial + (int64_t)base * g.n_slabs * g.n_tiles * 4096;
+    if (g.stream) {
+      if (d_row_off)
+        hipLaunchKernelGGL((gram64_stream_kernel<TIN, true>), dim3(1, g.n_slabs, count), dim3(256), 0, s, ptrs, m, lda, part,
+                           g.rows_per_slab, d_row_off, d_col_off);
+      else
+        hipLaunchKernelGGL((gram64_stream_kernel<TIN, false>), dim3(1, g.n_slabs, count), dim3(256), 0, s, ptrs, m, lda, part,
+                           g.rows_per_slab, d_row_off, d_col_off);
+    } else
     hipLaunchKernelGGL((gram_wide_batched_kernel<64, TIN>), dim3(g.n_tiles, g.n_slabs, count), dim3(256), 0, s, ptrs, m, n, lda,
                        part, g.tiles_1d, g.rows_per_slab, vec_ok, d_row_off, d_col_off);
     hipLaunchKernelGGL(tile_reduce_batched_kernel<64>, dim3(g.n_tiles, 16, count), dim3(256), 0, s, part, g.n_slabs, g.tiles_1d,
