@@ -518,6 +518,13 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
   long long t_start = wall_clock64();
   __syncthreads();
 
+#ifdef NDMPS_TEAM_STAMPS
+  long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TEAM_STAMP(k) { const long long now_ = (long long)__builtin_readcyclecounter(); st[k] += now_ - last_; last_ = now_; }
+  long long last_ = (long long)__builtin_readcyclecounter();
+#else
+#define TEAM_STAMP(k)
+#endif
   for (int j = 0; j <= j_last; ++j) {
     // ---- operands of the prologue: y of step j - 1 and column j (both published before the last meeting)
     double yv[NR], rj[NR];
@@ -578,6 +585,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
         rj[r] = i < n ? A[i] : 0.0;
       }
     }
+    TEAM_STAMP(0)
     // ---- prologue a: w' of step j - 1
     double dot = 0.0;
 #pragma unroll
@@ -597,6 +605,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     } else {
       __syncthreads();
     }
+    TEAM_STAMP(1)
     dot = (red_a[0] + red_a[1]) + (red_a[2] + red_a[3]);
     const double al = 0.5 * taup * taup * dot;
     const double wpj = taup * y_j - al;  // v'[j] = 1
@@ -613,6 +622,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     sigma = wave_sum(sigma);
     if (lane == 0) red_b[wave] = sigma;
     __syncthreads();
+    TEAM_STAMP(2)
     sigma = (red_b[0] + red_b[1]) + (red_b[2] + red_b[3]);
     const double alpha = r_j1 - ((taup * y_j1 - al * v_j1) + wpj * v_j1);
     double beta, tau, scale;
@@ -642,6 +652,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     }
     taup = tau;
     __syncthreads();
+    TEAM_STAMP(3)
 
     // ---- body: pending update applied in the registers, column sums with the new reflector
     double wc[4], vc[4];
@@ -653,10 +664,14 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     }
     const int u0 = (j + 1) / RPI;  // tiles made of finished rows only
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // the row record of a tile is fetched two tiles ahead, outside the (uniform) branch that skips finished tiles
+    RowVec rec0 = rv[row0], rec1 = rv[row0 + RPI];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
+      const RowVec rec = rec0;
+      rec0 = rec1;
+      if (u + 2 < NT) rec1 = rv[row0 + RPI * (u + 2)];
       if (u >= u0) {
-        const RowVec rec = rv[row0 + RPI * u];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           a[u][k] = fma(-rec.wp, vc[k], fma(-rec.vp, wc[k], a[u][k]));
@@ -664,6 +679,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
         }
       }
     }
+    TEAM_STAMP(4)
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = ndmps_lanes::sum_adjacent<RPW>(acc[k]);
     if (q == 0) {
@@ -676,6 +692,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
       if (!TAGGED || j + 1 >= J) team_store(ybuf + (j & 1) * lda + c0 + tid, yc);  // plain vector: the tail kernel reads it
       if (TAGGED) rec_store(yr + (j & 1) * lda + c0 + tid, yc, tag_base | (unsigned long long)(j + 1));
     }
+    TEAM_STAMP(5)
     if (j + 1 >= J) break;  // the tail kernel continues from the stored matrix
     // ---- column j + 1 of the updated matrix, by its owner
     if (member == (j + 1) / CW) {
@@ -742,8 +759,13 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
       go = ok;
     }
     __syncthreads();
+    TEAM_STAMP(6)
     if (!go) return;
   }
+#ifdef NDMPS_TEAM_STAMPS
+  if (tid == 0 && member == nblk - 1)
+    for (int q = 0; q < 8; ++q) w.stamps[b * 16 + q] = st[q];
+#endif
 
   // ---- hand-over to the tail kernel: the trailing block as the column launches would have left it (updates
   //      through J - 2 applied, step J - 1 pending in y / Vh / tau)
