@@ -242,10 +242,14 @@ __device__ __forceinline__ Cf cmulni(Cf a) { return Cf{a.im, -a.re}; }  // -i a
 
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <bool INVERSE>
+// NN: the transform length as a compile-time constant (0: taken from the argument): stage count, strides and loop trip
+// counts fold into the instruction stream -- the kernel is bound by the instructions a wave issues per row, not by LDS
+// or HBM bandwidth (262144 rows of 512 in 378 us = 2.7 rows per us and CU against ~600 VALU instructions per row)
+template <bool INVERSE, int NN>
 __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows,
-                                                      int N) {
+                                                      int N_arg) {
   extern __shared__ __attribute__((aligned(16))) float fft_lds[];
+  const int N = NN ? NN : N_arg;
   const int M = N / 2;
   Cf* twM = reinterpret_cast<Cf*>(fft_lds);  // exp(-2 pi i t / M), t < M
   Cf* wN = twM + M;                          // exp(-2 pi i k / N), k <= M
@@ -272,28 +276,51 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
   // from here on every wave works on LDS buffers of its own, row after row: ordering inside the wave is all that is
   // needed between a stage's writes and the next stage's reads (LDS operations of one wave complete in order)
   const int64_t per_round = (int64_t)gridDim.x * 4;
+  // the next row of the wave is fetched while the current one is transformed (N <= 1024: four float4 per lane)
+  float4 nx[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                  make_float4(0.f, 0.f, 0.f, 0.f)};
+  auto fetch_row = [&](int64_t row) {
+    const float4* in4 = reinterpret_cast<const float4*>(src + row * N);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = lane + 64 * t;
+      if (i < N / 4 && row < rows) nx[t] = in4[i];
+    }
+  };
+  fetch_row((int64_t)blockIdx.x * 4 + wave);
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += per_round) {
     constexpr bool on = true;
-    if (on) {
-      const float4* in4 = reinterpret_cast<const float4*>(src + row * N);
-      float4* rb4 = reinterpret_cast<float4*>(rowbuf);
-      for (int i = lane; i < N / 4; i += 64) rb4[i] = in4[i];
-    }
-    wave_lds_sync();
     Cf* a = bufA;
     Cf* b = bufB;
+    if (!INVERSE) {
+      // Makhoul's reordering straight from the registers: elements 4i .. 4i + 3 are v[2i] = x[4i], v[2i + 1] = x[4i + 2] and,
+      // from the far end, v[N - 1 - 2i] = x[4i + 1], v[N - 2 - 2i] = x[4i + 3]; packed as z[n] = v[2n] + i v[2n + 1]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = lane + 64 * t;
+        if (i < N / 4) {
+          a[i] = Cf{nx[t].x, nx[t].z};
+          a[M - 1 - i] = Cf{nx[t].w, nx[t].y};
+        }
+      }
+    } else {
+      float4* rb4 = reinterpret_cast<float4*>(rowbuf);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = lane + 64 * t;
+        if (i < N / 4) rb4[i] = nx[t];
+      }
+    }
+    fetch_row(row + per_round);
+    wave_lds_sync();
     if (on) {
       if (!INVERSE) {
-        for (int n = lane; n < M; n += 64) {
-          Cf z;
-          if (n < N / 4) z = Cf{rowbuf[4 * n], rowbuf[4 * n + 2]};
-          else z = Cf{rowbuf[2 * N - 1 - 4 * n], rowbuf[2 * N - 3 - 4 * n]};
-          a[n] = z;
-        }
       } else {
         // V[k] = conj(wQ[k]) (X[k] - i X[N-k]) / s;  Z[k] = E + i O,  E = (V[k] + conj V[M-k]) / 2,
-        // O = conj(W_N^k) (V[k] - conj V[M-k]) / 2
-        for (int k = lane; k < M; k += 64) {
+        // O = conj(W_N^k) (V[k] - conj V[M-k]) / 2 -- and Z[M-k] = conj(E) + i conj(O) (W_N^{M-k} = -conj W_N^k): one
+        // pair (V[k], V[M-k]) serves both entries, k = 0 .. M / 2
+#pragma unroll
+        for (int k = lane; k <= M / 2; k += 64) {
           auto vk = [&](int q) {
             const float xr = rowbuf[q] * (q == 0 ? 1.0f / s0 : 1.0f / s1);
             const float xi = q == 0 ? 0.0f : rowbuf[N - q] * (1.0f / s1);
@@ -304,16 +331,20 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
           const Cf d = Cf{0.5f * (v1.re - v2.re), 0.5f * (v1.im - v2.im)};
           const Cf o = cmul(cconj(wN[k]), d);
           a[k] = cadd(e, cmuli(o));
+          if (k >= 1 && 2 * k != M) a[M - k] = cadd(cconj(e), cmuli(cconj(o)));
         }
       }
     }
     wave_lds_sync();
     const int lm = 31 - __builtin_clz(M);  // M = 2^lm
-    for (int ls = 0; ls < lm;) {           // Ns = 2^ls: length of the finished sub-transforms
+#pragma unroll
+    for (int stage = 0; stage < (lm + 1) / 2; ++stage) {  // radix-4 stages, a radix-2 one at the end of an odd lm
+      const int ls = 2 * stage;          // Ns = 2^ls: length of the finished sub-transforms
       const int Ns = 1 << ls;
       const int lr = (lm - ls) >= 2 ? 2 : 1, R = 1 << lr;
       if (on) {
         const int span = M >> lr;
+#pragma unroll
         for (int j = lane; j < span; j += 64) {
           const int k = j & (Ns - 1);
           const int j0 = ((j >> ls) << (ls + lr)) + k;
@@ -349,34 +380,43 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
       Cf* sw = a;
       a = b;
       b = sw;
-      ls += lr;
     }
     if (on) {
       if (!INVERSE) {
-        for (int k = lane; k <= M; k += 64) {
-          const Cf zk = a[k == M ? 0 : k], zc = cconj(a[k == 0 ? 0 : M - k]);
+        // v[k] = E + g, g = -i W_N^k D with E, D = (z[k] +- conj z[M-k]) / 2, and v[M-k] = conj(E - g): one pair serves
+        // k and M - k (z[M] := z[0]), k = 0 .. M / 2; X[k] = Re(wQ[k] v[k]) s, X[N-k] = -Im(wQ[k] v[k]) s
+#pragma unroll
+        for (int k = lane; k <= M / 2; k += 64) {
+          const Cf zk = a[k], zc = cconj(a[k == 0 ? 0 : M - k]);
           const Cf e = Cf{0.5f * (zk.re + zc.re), 0.5f * (zk.im + zc.im)};
           const Cf d = Cf{0.5f * (zk.re - zc.re), 0.5f * (zk.im - zc.im)};
-          const Cf v = cadd(e, cmul(wN[k], cmulni(d)));
-          const Cf t = cmul(wQ[k], v);
-          rowbuf[k] = t.re * (k == 0 ? s0 : s1);
-          if (k >= 1 && k < M) rowbuf[N - k] = -t.im * s1;
-        }
-      } else {
-        const float inv = 1.0f / (float)M;
-        for (int n = lane; n < M; n += 64) {
-          const Cf z = a[n];
-          // v[2n] = Re z, v[2n+1] = Im z;  x[2m] = v[m], x[2m+1] = v[N-1-m]
-          const int m0 = 2 * n, m1 = 2 * n + 1;
-          rowbuf[m0 < M ? 2 * m0 : 2 * (N - 1 - m0) + 1] = z.re * inv;
-          rowbuf[m1 < M ? 2 * m1 : 2 * (N - 1 - m1) + 1] = z.im * inv;
+          const Cf g = cmul(wN[k], cmulni(d));
+          const Cf t1 = cmul(wQ[k], cadd(e, g));
+          rowbuf[k] = t1.re * (k == 0 ? s0 : s1);
+          if (k >= 1) rowbuf[N - k] = -t1.im * s1;
+          if (2 * k != M) {
+            const Cf t2 = cmul(wQ[M - k], cconj(csub(e, g)));
+            rowbuf[M - k] = t2.re * s1;
+            if (k >= 1) rowbuf[M + k] = -t2.im * s1;  // N - (M - k)
+          }
         }
       }
     }
-    wave_lds_sync();
-    if (on) {
+    if (INVERSE) {
+      // x[4i .. 4i + 3] = (v[2i], v[N - 1 - 2i], v[2i + 1], v[N - 2 - 2i]) = (Re z[i], Im z[M-1-i], Im z[i], Re z[M-1-i]):
+      // straight from the last stage's buffer to a coalesced 16-byte store
+      const float inv = 1.0f / (float)M;
+      float4* out4 = reinterpret_cast<float4*>(dst + row * N);
+#pragma unroll
+      for (int i = lane; i < N / 4; i += 64) {
+        const Cf zi = a[i], zj = a[M - 1 - i];
+        out4[i] = make_float4(zi.re * inv, zj.im * inv, zi.im * inv, zj.re * inv);
+      }
+    } else {
+      wave_lds_sync();
       float4* out4 = reinterpret_cast<float4*>(dst + row * N);
       const float4* rb4 = reinterpret_cast<const float4*>(rowbuf);
+#pragma unroll
       for (int i = lane; i < N / 4; i += 64) out4[i] = rb4[i];
     }
     wave_lds_sync();
@@ -387,18 +427,27 @@ inline bool dct_fft_ok(int64_t rows, int64_t n, const void* a, const void* b) {
   return n >= 64 && n <= 1024 && (n & (n - 1)) == 0 && rows >= 1 && (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0 &&
          !getenv("NDMPS_DCT_GEMM");
 }
-template <bool INVERSE>
-int dct_fft_launch(const float* src, float* dst, int64_t rows, int64_t n, hipStream_t s) {
+template <bool INVERSE, int NN>
+int dct_fft_launch_n(const float* src, float* dst, int64_t rows, int64_t n, hipStream_t s) {
   const int M = (int)n / 2;
   const size_t lds = (size_t)(M + 2 * (M + 1)) * sizeof(Cf) + (size_t)4 * (n + 4 * M) * sizeof(float);
   // exactly the workgroups the device keeps resident at once (every workgroup loops over rows: a partly filled second
   // round of workgroups would leave a third of the GPU idle for half the kernel)
   int per_cu = 0;
-  NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dct_fft_kernel<INVERSE>, 256, lds));
+  NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dct_fft_kernel<INVERSE, NN>, 256, lds));
   const int grid = (int)std::min<int64_t>((rows + 3) / 4, (int64_t)ndmps::kNumCU * std::max(per_cu, 1));
-  hipLaunchKernelGGL(dct_fft_kernel<INVERSE>, dim3(grid), dim3(256), lds, s, src, dst, rows, (int)n);
+  hipLaunchKernelGGL((dct_fft_kernel<INVERSE, NN>), dim3(grid), dim3(256), lds, s, src, dst, rows, (int)n);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
+}
+template <bool INVERSE>
+int dct_fft_launch(const float* src, float* dst, int64_t rows, int64_t n, hipStream_t s) {
+  switch (n) {  // the volume edges that occur: constants; anything else: the generic kernel
+    case 128: return dct_fft_launch_n<INVERSE, 128>(src, dst, rows, n, s);
+    case 256: return dct_fft_launch_n<INVERSE, 256>(src, dst, rows, n, s);
+    case 512: return dct_fft_launch_n<INVERSE, 512>(src, dst, rows, n, s);
+    default: return dct_fft_launch_n<INVERSE, 0>(src, dst, rows, n, s);
+  }
 }
 
 int stream_grid(int64_t n) {
