@@ -109,6 +109,7 @@ class _Plan:
 
         self._split = {}
         self._split_vec4 = {}
+        self._sorted_rows = {}
 
     def split_tables(self, n_cols, device):
         """Device tables for the site-order tensor viewed as (numel / n_cols) x n_cols: element (r, c) sits at
@@ -136,6 +137,19 @@ class _Plan:
                                     torch.from_numpy(perm.astype(np.int32)).to(device))
                 torch.cuda.synchronize(device)
             return self._split[key]
+
+    def sorted_rows(self, n_cols, device):
+        """split_tables' row offsets in ascending order (int64 device tensor): the order in which the Gram kernels of
+        the fused sweep visit the rows -- a Gram matrix is a sum over rows -- so that they read the volume front to
+        back.  Built once per (n_cols, device)."""
+        torch = _torch()
+        key = (int(n_cols), str(device))
+        row_off = self.split_tables(n_cols, device)[0]
+        with _CACHE_LOCK:
+            if key not in self._sorted_rows:
+                self._sorted_rows[key] = torch.sort(row_off)[0].contiguous()
+                torch.cuda.synchronize(device)
+            return self._sorted_rows[key]
 
     def gather_tables(self, n_cols, device):
         """split_tables when the volume can be read through them 16 bytes at a time, else None."""
@@ -500,10 +514,11 @@ class NDMPS:
             with _span("sweep"):
                 if gather is not None:
                     row_off, col_off, col_perm = gather
+                    row_sorted = plan.sorted_rows(n_merge, device)
                     _lib.check(lib.ndmps_tt_sweep_batched_fused_f32(
                         batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds, spectra, spec_off,
-                        row_off.data_ptr(), col_off.data_ptr(), col_perm.data_ptr(), n_merge, ws.data_ptr(), ws.numel(),
-                        stream))
+                        row_off.data_ptr(), row_sorted.data_ptr(), col_off.data_ptr(), col_perm.data_ptr(), n_merge,
+                        ws.data_ptr(), ws.numel(), stream))
                 else:
                     sweep = (lib.ndmps_tt_sweep_batched_bf16 if bf16 else
                              lib.ndmps_tt_sweep_batched_f64 if f64 else lib.ndmps_tt_sweep_batched_f32)

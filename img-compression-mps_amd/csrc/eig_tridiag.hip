@@ -664,19 +664,22 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     }
     const int u0 = (j + 1) / RPI;  // tiles made of finished rows only
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    // the row record of a tile is fetched two tiles ahead, outside the (uniform) branch that skips finished tiles
-    RowVec rec0 = rv[row0], rec1 = rv[row0 + RPI];
+    // finished tiles are skipped in PAIRS (one uniform branch per pair): a basic block then holds two tiles -- eight
+    // independent FMA chains, both row records in flight together.  A finished tile inside a live pair is updated like
+    // the other one: its rows have v_j = 0 and are never read again (half a tile of extra work per column on average).
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const RowVec rec = rec0;
-      rec0 = rec1;
-      if (u + 2 < NT) rec1 = rv[row0 + RPI * (u + 2)];
-      if (u >= u0) {
+    for (int g = 0; g < NT / 2; ++g) {
+      if (2 * g + 1 >= u0) {
+        const RowVec ra = rv[row0 + RPI * (2 * g)], rb = rv[row0 + RPI * (2 * g + 1)];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          a[u][k] = fma(-rec.wp, vc[k], fma(-rec.vp, wc[k], a[u][k]));
-          acc[k] = fma(a[u][k], rec.vj, acc[k]);
+          a[2 * g][k] = fma(-ra.wp, vc[k], fma(-ra.vp, wc[k], a[2 * g][k]));
+          a[2 * g + 1][k] = fma(-rb.wp, vc[k], fma(-rb.vp, wc[k], a[2 * g + 1][k]));
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fma(a[2 * g][k], ra.vj, acc[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fma(a[2 * g + 1][k], rb.vj, acc[k]);
       }
     }
     TEAM_STAMP(4)

@@ -272,6 +272,8 @@ gather_rows_kernel(const float* __restrict__ W, int64_t rows, int64_t cols, cons
 
 struct SweepSource {           // the volume read through the index permutation (fp32, merged run only)
   const int64_t* row_off;      // [numel / n_cols]
+  const int64_t* row_sorted;   // the same offsets in ascending order: the Gram kernels -- a sum over rows -- read the volume
+                               // front to back (16-byte pieces of adjacent rows are neighbours in memory); may equal row_off
   const int64_t* col_off;      // [n_cols], ascending, aligned runs of four consecutive offsets
   const int32_t* col_perm;     // [n_cols]
   int64_t n_cols;
@@ -494,7 +496,7 @@ inline int gram_batched_src(int, const double* const*, int64_t, int64_t, const S
 }
 inline int gram_batched_src(int batch, const float* const* vol, int64_t m, int64_t n, const SweepSource& src, double* G,
                             int64_t stride, void* ws, int64_t wsb, hipStream_t s) {
-  return ndmps_gram_batched_indexed_f32(batch, vol, m, n, src.row_off, src.col_off, src.col_perm, G, stride, ws, wsb, s);
+  return ndmps_gram_batched_indexed_f32(batch, vol, m, n, src.row_sorted, src.col_off, src.col_perm, G, stride, ws, wsb, s);
 }
 inline int gram_batched_src(int, const __bf16* const*, int64_t, int64_t, const SweepSource&, double*, int64_t, void*,
                             int64_t, hipStream_t) {
@@ -546,7 +548,7 @@ inline bool gemm_batched_T(int, int, int64_t, int64_t, int64_t, __bf16* const*, 
 // fp32 only: Gram and projection of the merged run through the permutation tables
 inline int gram_src(const float* vol, int64_t m, int64_t n, const SweepSource& src, double* G, void* ws, int64_t wsb,
                     hipStream_t s) {
-  return ndmps_gram_indexed_f32(vol, m, n, src.row_off, src.col_off, src.col_perm, G, ws, wsb, s);
+  return ndmps_gram_indexed_f32(vol, m, n, src.row_sorted, src.col_off, src.col_perm, G, ws, wsb, s);
 }
 inline int gram_src(const __bf16*, int64_t, int64_t, const SweepSource&, double*, void*, int64_t, hipStream_t) {
   ndmps::set_error("the fused reshape stage is fp32 only");
@@ -1092,11 +1094,11 @@ extern "C" int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h
                                                 double cutoff, int64_t max_bond, float* const* h_cores,
                                                 const int64_t* h_core_offsets, int64_t* h_bonds_out,
                                                 double* h_spectra, const int64_t* h_spec_offsets,
-                                                const int64_t* d_row_off, const int64_t* d_col_off,
-                                                const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
-                                                int64_t ws_bytes, ndmps_stream_t stream) {
+                                                const int64_t* d_row_off, const int64_t* d_row_off_sorted,
+                                                const int64_t* d_col_off, const int32_t* d_col_perm, int64_t n_cols,
+                                                void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_row_off && d_col_off && d_col_perm && n_cols >= 1, "NULL permutation table");
-  SweepSource src{d_row_off, d_col_off, d_col_perm, n_cols};
+  SweepSource src{d_row_off, d_row_off_sorted ? d_row_off_sorted : d_row_off, d_col_off, d_col_perm, n_cols};
   return retry_without_team([&]() {
     return sweep_impl<float>(batch, (float* const*)h_volume, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets,
                              h_bonds_out, h_spectra, h_spec_offsets, d_ws, ws_bytes, stream, &src);

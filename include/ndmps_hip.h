@@ -328,10 +328,13 @@ int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h_volume, in
                                      double cutoff, int64_t max_bond, float* const* h_cores,
                                      const int64_t* h_core_offsets, int64_t* h_bonds_out,
                                      double* h_spectra, const int64_t* h_spec_offsets,
-                                     const int64_t* d_row_off, const int64_t* d_col_off,
-                                     const int32_t* d_col_perm, int64_t n_cols, void* d_ws,
-                                     int64_t ws_bytes, ndmps_stream_t stream);
-/* G = A^T A where element (r, c) of A is d_base[d_row_off[r] + d_col_off[c]] (wide path: n >= 64, m >= 256);
+                                     const int64_t* d_row_off, const int64_t* d_row_off_sorted,
+                                     const int64_t* d_col_off, const int32_t* d_col_perm, int64_t n_cols,
+                                     void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+/* d_row_off_sorted (may be NULL): the entries of d_row_off in ascending order.  A Gram matrix is a sum over rows, so
+ * its kernels may visit them in any order; in ascending order of their offsets they read the volume front to back
+ * (32 x 262144 x 64: 1.14 -> 0.74 ms).  The projection keeps d_row_off (its output rows are the rows).
+ * G = A^T A where element (r, c) of A is d_base[d_row_off[r] + d_col_off[c]] (wide path: n >= 64, m >= 256);
  * d_col_perm (may be NULL): entry (a, b) of the product is stored at G[d_col_perm[a]][d_col_perm[b]] -- the columns
  * were visited in the memory order of the volume, the result comes out in site order */
 int ndmps_gram_indexed_f32(const float* d_base, int64_t m, int64_t n, const int64_t* d_row_off,
