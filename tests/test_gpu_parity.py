@@ -212,11 +212,12 @@ def test_gemm_batched_equals_gemm_per_triple(batch, m, n, k, ta, tb):
 
 
 @pytest.mark.parametrize("batch,m,n", [(1, 4096, 512), (3, 1000, 200), (5, 300, 128), (32, 512, 512), (2, 20000, 384),
-                                       (4, 257, 131), (32, 32768, 64), (3, 5000, 64), (2, 300, 100), (70, 700, 96)])
+                                       (4, 257, 131), (32, 32768, 64), (3, 5000, 64), (2, 300, 100), (70, 700, 96), (2, 4099, 64), (66, 260, 64)])
 def test_gram_batched_fp64(batch, m, n):
-    """One launch for the Gram matrices of a group (n >= 128: 128 x 128 tiles; 64 <= n < 128 and at least two
-    matrices: 64 x 64 tiles, the raw Gram of a bond cap of 32): exactly symmetric, fp64-accurate, and reproducible
-    (a second call gives the same bits)."""
+    """One launch for the Gram matrices of a group (n >= 128: 128 x 128 tiles; 64 < n < 128 and at least two
+    matrices: 64 x 64 tiles; n == 64, the raw Gram of a bond cap of 32: the streaming kernel, with row counts that
+    are and are not multiples of its 16-row steps and 128-row blocks, more than 64 matrices): exactly symmetric,
+    fp64-accurate, and reproducible (a second call gives the same bits)."""
     lib = _lib.load()
     rng = np.random.default_rng(batch + m + n)
     mats = [dev(rng.standard_normal((m, n)).astype(np.float32), torch.float32) for _ in range(batch)]
@@ -1541,7 +1542,8 @@ def test_degenerate_inputs_match_the_oracle(name, kw):
         assert np.abs(rg - x).max() <= 2e-6 * scale
 
 
-@pytest.mark.parametrize("m,n,batch", [(4096, 512, 1), (2048, 256, 3), (1024, 96, 1), (600, 64, 1), (8192, 64, 5), (900, 96, 2)])
+@pytest.mark.parametrize("m,n,batch", [(4096, 512, 1), (2048, 256, 3), (1024, 96, 1), (600, 64, 1), (8192, 64, 5), (900, 96, 2), (8203, 64, 3),
+                                           (300, 64, 2)])
 def test_gathered_gram_stores_its_result_through_the_column_permutation(m, n, batch):
     """The raw Gram of the fused sweep visits the columns in memory order (d_col_off ascending) and its slab
     reduction stores entry (a, b) at G[perm[a]][perm[b]]: the result equals the Gram of the gathered matrix with

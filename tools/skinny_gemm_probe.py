@@ -51,7 +51,14 @@ core = [torch.randn(64, 512, device=dev) for _ in range(batch)]
 nxt = [torch.empty(4096 * 64, device=dev) for _ in range(batch)]
 sa, sb, sc = ptrs(carry), ptrs(core), ptrs(nxt)
 
+order = torch.argsort(row_off[:m0])
+row_sorted = row_off[:m0][order].contiguous()
+c_rows = (order * 64).contiguous()
+c_cols = torch.arange(64, device=dev, dtype=torch.int64)
 cases = (
+    ("first projection, rows in memory order", 2.0 * numel * 64 * batch, 4.0 * numel * batch * 1.125,
+     lambda: _lib.check(lib.ndmps_sgemm_indexed_batched(batch, m0, 64, 512, pa, 0, row_sorted.data_ptr(), col_off.data_ptr(), 1,
+                                                        pb, 64, pc, 64, c_rows.data_ptr(), c_cols.data_ptr(), sp()))),
     ("first projection (gathered A)", 2.0 * numel * 64 * batch, 4.0 * numel * batch * 1.125,
      lambda: _lib.check(lib.ndmps_sgemm_indexed_batched(batch, m0, 64, 512, pa, 0, row_off.data_ptr(), col_off.data_ptr(), 1,
                                                         pb, 64, pc, 64, None, None, sp()))),
