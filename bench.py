@@ -45,8 +45,8 @@ FIRST_SEED = 2025  # the reference tests' seed; volume j of the job u
 
 # BASELINE.json configs[1..4] and the metric's own configuration; flags given on the command line override a field
 CONFIGS = {
-    "metric": {"kind": "cubes", "size": 256, "chi": 64, "mode": "Std", "batch": 64, "groups": 2, "total_volumes": 0},
-    "2": {"kind": "cubes", "size": 256, "chi": 32, "mode": "Std", "batch": 64, "groups": 2, "total_volumes": 0},
+    "metric": {"kind": "cubes", "size": 256, "chi": 64, "mode": "Std", "batch": 64, "groups": 0, "total_volumes": 0},
+    "2": {"kind": "cubes", "size": 256, "chi": 32, "mode": "Std", "batch": 64, "groups": 0, "total_volumes": 0},
     "3": {"kind": "cubes", "size": 512, "chi": 64, "mode": "DCT", "batch": 8, "groups": 1, "total_volumes": 0},
     "4": {"kind": "cubes", "size": 128, "chi": 32, "mode": "Std", "batch": 64, "groups": 1, "total_volumes": 64},
     "5": {"kind": "tensor", "shape": (128, 128, 64, 256), "chi": 128, "mode": "Std", "batch": 1, "groups": 1,
@@ -69,7 +69,7 @@ def parse(argv=None):
                     help="strong scaling: this many volumes IN TOTAL per step, sharded over the ranks")
     ap.add_argument("--groups", type=int, default=None,
                     help="concurrent groups (host thread + HIP stream each) the rank's volumes are cut into; "
-                         "volumes of a group are encoded in lockstep")
+                         "volumes of a group are encoded in lockstep (0 / not given: two from 32 volumes per GPU on, else one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="profiling aid: the timed loop only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -95,11 +95,16 @@ def job_descriptor(args, world):
     and 5): the job is `total_volumes` volumes whatever the number of ranks."""
     strong = int(args.total_volumes) > 0
     n_volumes = int(args.total_volumes) if strong else int(args.batch) * int(world)
+    per_gpu = -(-n_volumes // int(world)) if strong else int(args.batch)
+    groups = int(args.groups)
+    if groups <= 0:  # not given: what the library would pick for this many volumes per GPU (core/batch.default_groups)
+        from imgcompressionmps_amd.core.batch import default_groups
+        groups = default_groups(per_gpu)
     return {"config": str(getattr(args, "config", "metric")), "kind": str(getattr(args, "kind", "cubes")),
             "shape": [int(v) for v in getattr(args, "shape", (args.size,) * 3)],
             "size": int(args.size), "chi": int(args.chi), "mode": str(args.mode),
             "batch_per_gpu": -(-n_volumes // int(world)) if strong else int(args.batch),
-            "groups": int(args.groups), "world": int(world), "first_seed": FIRST_SEED,
+            "groups": groups, "world": int(world), "first_seed": FIRST_SEED,
             "n_volumes": n_volumes, "scaling": "strong" if strong else "weak"}
 
 

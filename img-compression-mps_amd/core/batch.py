@@ -40,6 +40,14 @@ def conv_to_mps(tensor_list: Sequence, mode: str = "DCT", norm: bool = False, ma
             for t in tensor_list]
 
 
+def default_groups(n_items: int) -> int:
+    """Concurrent lockstep groups for ``n_items`` same-shape volumes on one GPU: two from 32 volumes on (each group's
+    single-workgroup solver kernels then hide under the other's throughput kernels: 64 volumes of 256^3 28 ms against
+    32), one below (two groups of 12 take 17.4 ms per step where one of 24 takes 15.6: the resident
+    tridiagonalisations of the groups exclude each other and cost the same for 12 matrices as for 24)."""
+    return 2 if n_items >= 32 else 1
+
+
 def _split(n_items: int, groups: int):
     groups = max(1, min(groups, n_items))
     return [shard_indices(n_items, g, groups) for g in range(groups)]
@@ -70,14 +78,14 @@ def group_streams(n: int):
     return _group_streams[key]
 
 
-def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str = "Std", norm: bool = False,
+def encode_decode_concurrent(tensor_list: Sequence, groups: int = None, mode: str = "Std", norm: bool = False,
                              max_bond=None, cutoff: float = 1e-10, reconstruct: bool = True, pool=None,
                              wait: bool = True):
     """Throughput path for a list of same-shape device volumes: the list is cut into ``groups``
     contiguous groups; every group runs on its own host thread and HIP stream and encodes its
     volumes in lockstep (``NDMPS.from_tensors``).  The eigen-solver phases of a group keep only a
     fraction of the chip busy, so several groups in flight overlap them with each other's
-    streaming phases (measured on MI355X: 8 volumes in flight 3.1, 16 -> 4.5, 32 -> 5.3 Gvoxel/s).
+    streaming phases; ``groups=None``: ``default_groups(len(tensor_list))``.
     Returns (list of NDMPS, list of reconstructions or None) in input order; every group's work has
     completed on the device when the call returns -- unless ``wait=False``: then the reconstructions are
     still being written on the groups' streams when the call returns (the NDMPS objects are complete) and the
@@ -89,6 +97,8 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = 4, mode: str =
     from .ndmps import NDMPS
 
     tensor_list = list(tensor_list)
+    if groups is None:
+        groups = default_groups(len(tensor_list))
     parts = _split(len(tensor_list), groups)
     main = torch.cuda.current_stream()
     ready = torch.cuda.Event()

@@ -55,7 +55,14 @@ order = torch.argsort(row_off[:m0])
 row_sorted = row_off[:m0][order].contiguous()
 c_rows = (order * 64).contiguous()
 c_cols = torch.arange(64, device=dev, dtype=torch.int64)
+order2 = torch.argsort(r_off[:4096])
+r_sorted = r_off[:4096][order2].contiguous()
+a_rows = (order2 * 64).contiguous()
+a_cols = torch.arange(64, device=dev, dtype=torch.int64)
 cases = (
+    ("last chain product, rows in memory order", 2.0 * numel * 64 * batch, 4.0 * numel * batch,
+     lambda: _lib.check(lib.ndmps_sgemm_indexed_batched(batch, 4096, 4096, 64, qa, 64, a_rows.data_ptr(), a_cols.data_ptr(), 1, qb, 4096, qc, 0,
+                                                        r_sorted.data_ptr(), c_off.data_ptr(), sp()))),
     ("first projection, rows in memory order", 2.0 * numel * 64 * batch, 4.0 * numel * batch * 1.125,
      lambda: _lib.check(lib.ndmps_sgemm_indexed_batched(batch, m0, 64, 512, pa, 0, row_sorted.data_ptr(), col_off.data_ptr(), 1,
                                                         pb, 64, pc, 64, c_rows.data_ptr(), c_cols.data_ptr(), sp()))),
