@@ -2231,7 +2231,7 @@ std::atomic<long long> g_team_fallbacks{0};
 std::atomic<int> g_inject_abort{0};
 
 constexpr bool kTeamXcdDefault = true;   // teams placed XCD by XCD (team_place) when NDMPS_TRD_XCD is not set
-constexpr bool kSymDefault = false;  // half-storage team kernel for nine matrices and more when NDMPS_TRD_SYM is not set
+constexpr bool kSymDefault = false;  // half-storage team kernel (batches beyond half the workgroup slots) when NDMPS_TRD_SYM is not set
 constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction when NDMPS_TRD_BAND is not set (0: off)
 
 // kernels that need more than 64 KB of dynamic LDS are opted in once per device
@@ -2384,8 +2384,9 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
     NDMPS_TRY(team_slots(slots));
     // one to four matrices: 8-column blocks (64 workgroups per order-512 matrix, one per CU)
     const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= slots && !getenv("NDMPS_TRD_TEAM_WIDE");
-    // nine matrices and more: half storage (eig_sym.inc), 8 workgroups per order-512 matrix -- a group of 32 takes one
-    // workgroup slot per CU and shares the GPU with the other group's reduction or kernels
+    // opt-in, batches that fill more than half the slots (17 order-512 matrices and more): half storage (eig_sym.inc),
+    // 8 workgroups per order-512 matrix -- a group of 32 takes one workgroup slot per CU and shares the GPU with the
+    // other group's reduction or kernels
     const char* sym_env = getenv("NDMPS_TRD_SYM");
     const bool sym = !narrow_team && n_max <= 512 && (sym_env ? atoi(sym_env) != 0 : kSymDefault) &&
                      (int64_t)batch * ndmps::ceil_div(n_max, 32) > slots / 2;
