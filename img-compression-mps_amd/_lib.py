@@ -66,8 +66,10 @@ SIGNATURES = {
     "ndmps_convert_f32_to_bf16": (C.c_int, [vp, i64, vp, vp]),
     "ndmps_tt_merge_columns": (i64, [C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_fused_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
-                                                   C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, vp, vp, vp, i64,
+                                                   C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, vp, vp, vp, vp, i64,
                                                    vp, i64, vp]),
+    "ndmps_sgemm_gathered64_stream_batched": (C.c_int, [C.c_int, i64, i64, C.POINTER(vp), vp, vp, vp, C.POINTER(vp), i64,
+                                                        C.POINTER(vp), i64, vp]),
     "ndmps_gram_indexed_f32": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, i64, vp]),
     "ndmps_tt_sweep_batched_bf16": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
                                               C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, i64, vp]),

@@ -139,15 +139,16 @@ class _Plan:
             return self._split[key]
 
     def sorted_rows(self, n_cols, device):
-        """split_tables' row offsets in ascending order (int64 device tensor): the order in which the Gram kernels of
-        the fused sweep visit the rows -- a Gram matrix is a sum over rows -- so that they read the volume front to
-        back.  Built once per (n_cols, device)."""
+        """(split_tables' row offsets in ascending order, int64; the row each of them belongs to, int32): the order in
+        which the Gram kernels and the streamed projection of the fused sweep visit the rows, so that they read the
+        volume front to back.  Built once per (n_cols, device)."""
         torch = _torch()
         key = (int(n_cols), str(device))
         row_off = self.split_tables(n_cols, device)[0]
         with _CACHE_LOCK:
             if key not in self._sorted_rows:
-                self._sorted_rows[key] = torch.sort(row_off)[0].contiguous()
+                srt, order = torch.sort(row_off)
+                self._sorted_rows[key] = (srt.contiguous(), order.to(torch.int32).contiguous())
                 torch.cuda.synchronize(device)
             return self._sorted_rows[key]
 
@@ -514,11 +515,11 @@ class NDMPS:
             with _span("sweep"):
                 if gather is not None:
                     row_off, col_off, col_perm = gather
-                    row_sorted = plan.sorted_rows(n_merge, device)
+                    row_sorted, row_order = plan.sorted_rows(n_merge, device)
                     _lib.check(lib.ndmps_tt_sweep_batched_fused_f32(
                         batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds, spectra, spec_off,
-                        row_off.data_ptr(), row_sorted.data_ptr(), col_off.data_ptr(), col_perm.data_ptr(), n_merge,
-                        ws.data_ptr(), ws.numel(), stream))
+                        row_off.data_ptr(), row_sorted.data_ptr(), row_order.data_ptr(), col_off.data_ptr(),
+                        col_perm.data_ptr(), n_merge, ws.data_ptr(), ws.numel(), stream))
                 else:
                     sweep = (lib.ndmps_tt_sweep_batched_bf16 if bf16 else
                              lib.ndmps_tt_sweep_batched_f64 if f64 else lib.ndmps_tt_sweep_batched_f32)

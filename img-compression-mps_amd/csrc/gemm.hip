@@ -1483,6 +1483,97 @@ extern "C" int ndmps_dgemm_batched(int batch, int transA, int transB, int64_t m,
   return launch_gemm<double, 64, 64, 2, 2>(transA, transB, m, n, k, A, lda, A, ldb, Cn, ldc, s, &bp, batch);
 }
 
+// ----------------------------------------------------------------------------------
+// C = A W for A = a lockstep group's volumes read through the permutation tables as (m x 64) matrices -- the first
+// projection of a bond cap of 32 (BASELINE configs 2 and 4): a 64 MB stream per 256^3 volume, 96 MB with the result.
+// The tile kernel reads it at 2.8 TB/s (1.1 ms per group of 32).  Here, as in gram64_stream_kernel, a lane's 16-byte
+// load is four MFMA operands: lane (i, h) = (lane % 32, lane / 32) of v_mfma_f32_32x32x2_f32 takes columns
+// 8q + 4h .. 8q + 4h + 3 of row i of a 32-row tile (columns in memory order: aligned quads are contiguous), its
+// component c is the A operand of the k-pair {8q + c, 8q + 4 + c}; the matching W rows sit in LDS as 16-byte records
+// [q][h][j] = (W[8q + 4h + c][j])_c.  Rows are visited in ascending order of their offsets (d_row_sorted): the 32
+// lanes of a half-wave read 512 contiguous bytes; row s of that order is row d_row_order[s] of C.  No barrier in the
+// loop; the eight loads of the next tile are issued slot by slot as the current tile's steps consume theirs.
+// NB = n / 32 (n = 32 or 64 columns of W).
+namespace {
+template <int NB>
+__global__ void __launch_bounds__(256, 2)
+proj64_stream_kernel(GemmBatchPtrs ptrs, int64_t m, int64_t ldb, int64_t ldc, const int64_t* __restrict__ row_sorted,
+                     const int32_t* __restrict__ row_order, const int64_t* __restrict__ col_off, int64_t tiles_per_wg) {
+  constexpr int N = 32 * NB, Q = 8;
+  const float* A = static_cast<const float*>(ptrs.a[blockIdx.z]);
+  const float* W = static_cast<const float*>(ptrs.b[blockIdx.z]);
+  float* C = static_cast<float*>(ptrs.c[blockIdx.z]);
+  __shared__ __attribute__((aligned(16))) float Wp[Q * 2 * N * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 64 * N; e += 256) {
+    const int kidx = e / N, j = e % N;
+    const int q = kidx >> 3, h = (kidx >> 2) & 1, c = kidx & 3;
+    Wp[((q * 2 + h) * N + j) * 4 + c] = W[(int64_t)kidx * ldb + j];
+  }
+  __syncthreads();
+  const int li = lane & 31, h = lane >> 5;
+  int64_t coff[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) coff[q] = col_off[8 * q + 4 * h];
+  const int64_t n_tiles = (m + 31) / 32;
+  const int64_t t_begin = (int64_t)blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+  // this wave's tiles: t_begin + wave, + 4, ...; a tile index beyond the end repeats the last row (never stored)
+  auto row_offset = [&](int64_t t) { return row_sorted[min(32 * t + li, m - 1)]; };
+  int64_t t = t_begin + wave;
+  if (t >= t_end) return;
+  float4 ring[Q];
+  int64_t roff = row_offset(t), roff_next = row_offset(t + 4);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) ring[q] = load4_stream_f32(A + roff + coff[q]);
+  for (; t < t_end; t += 4) {
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+    const int64_t roff_after = row_offset(t + 8);
+    // the tile's sixteen output rows of this lane, requested before the next tile's loads (a load issued behind them,
+    // inside the guarded stores, would make every store wait for the whole ring)
+    int crow_of[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) crow_of[r] = row_order[min(32 * t + (r & 3) + 8 * (r >> 2) + 4 * h, m - 1)];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      // the step's operands leave the slot BEFORE it is reloaded in place (opaque copies: used from the slot itself, the
+      // last MFMAs of the step would read registers an already issued load may overwrite, and the compiler answers
+      // with a second set of registers and copies that wait for the loads they follow)
+      float4 a = ring[q];
+      asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+      float4 bq[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bq[nb] = *reinterpret_cast<const float4*>(&Wp[((q * 2 + h) * N + 32 * nb + li) * 4]);
+      __builtin_amdgcn_sched_barrier(0);
+      ring[q] = load4_stream_f32(A + roff_next + coff[q]);  // the same step of the wave's next tile
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[nb].x, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[nb].y, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[nb].z, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[nb].w, acc[nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    roff_next = roff_after;
+    // accumulator register r of lane (j, h) is row (r & 3) + 8 (r >> 2) + 4 h of the tile, column j
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t s = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (s < m) {
+        float* crow = C + (int64_t)crow_of[r] * ldc + li;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) crow[32 * nb] = acc[nb][r];
+      }
+    }
+  }
+}
+
+}  // namespace
+
 // batched C = A B with table-driven addressing (one set of tables for the whole batch: the volumes of a lockstep
 // group share the index permutation); see ndmps_sgemm_indexed
 extern "C" int ndmps_sgemm_indexed_batched(int batch, int64_t m, int64_t n, int64_t k, const float* const* h_A,
@@ -1519,6 +1610,35 @@ extern "C" int ndmps_sgemm_indexed_batched(int batch, int64_t m, int64_t n, int6
       hipLaunchKernelGGL((gemm_batched_kernel<float, 128, 128, 2, 2, false, false, false, true>), grid, block, 0, s, m,
                          n, k, bp, lda, ldb, ldc, ix);
   }
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
+}
+
+// The first projection of the fused sweep for 64 gathered columns, as a stream (proj64_stream_kernel): C[b] (m x n,
+// n = 32 or 64, row-major with leading dimension ldc) = A[b] W[b], element (r, c) of A[b] at
+// h_A[b][d_row_off[r] + d_col_off[c]].  d_row_sorted: d_row_off in ascending order; d_row_order[s]: the row whose offset
+// is d_row_sorted[s].  NDMPS_EINVAL for shapes the kernel does not take (the caller keeps ndmps_sgemm_indexed_batched).
+extern "C" int ndmps_sgemm_gathered64_stream_batched(int batch, int64_t m, int64_t n, const float* const* h_A,
+                                                     const int64_t* d_row_sorted, const int32_t* d_row_order,
+                                                     const int64_t* d_col_off, const float* const* h_B, int64_t ldb,
+                                                     float* const* h_C, int64_t ldc, ndmps_stream_t stream) {
+  GemmBatchPtrs bp;
+  NDMPS_TRY(gemm_batched_check(batch, h_A, h_B, h_C, bp));
+  NDMPS_REQUIRE(d_row_sorted && d_row_order && d_col_off, "NULL table");
+  NDMPS_REQUIRE(m >= 1 && (n == 32 || n == 64) && ldb >= n && ldc >= n, "the stream takes 32 or 64 result columns");
+  for (int z = 0; z < batch; ++z) NDMPS_REQUIRE((uintptr_t)bp.a[z] % 16 == 0, "operand %d is not 16-byte aligned", z);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = ndmps::ceil_div(m, 32);
+  // ~4 workgroups per CU over the batch (two resident), whole multiples of the four tiles a workgroup's waves take
+  const int64_t want = std::max<int64_t>(1, ndmps::ceil_div((int64_t)4 * ndmps::kNumCU, batch));
+  const int64_t tiles_per_wg = ndmps::round_up(std::max<int64_t>(ndmps::ceil_div(n_tiles, want), 4), 4);
+  const dim3 grid(1, (unsigned)ndmps::ceil_div(n_tiles, tiles_per_wg), (unsigned)batch);
+  if (n == 32)
+    hipLaunchKernelGGL(proj64_stream_kernel<1>, grid, dim3(256), 0, s, bp, m, ldb, ldc, d_row_sorted, d_row_order, d_col_off,
+                       tiles_per_wg);
+  else
+    hipLaunchKernelGGL(proj64_stream_kernel<2>, grid, dim3(256), 0, s, bp, m, ldb, ldc, d_row_sorted, d_row_order, d_col_off,
+                       tiles_per_wg);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }

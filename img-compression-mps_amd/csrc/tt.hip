@@ -274,6 +274,7 @@ struct SweepSource {           // the volume read through the index permutation 
   const int64_t* row_off;      // [numel / n_cols]
   const int64_t* row_sorted;   // the same offsets in ascending order: the Gram kernels -- a sum over rows -- read the volume
                                // front to back (16-byte pieces of adjacent rows are neighbours in memory); may equal row_off
+  const int32_t* row_order;    // row_sorted[s] = row_off[row_order[s]] (NULL: not given); the streamed projection
   const int64_t* col_off;      // [n_cols], ascending, aligned runs of four consecutive offsets
   const int32_t* col_perm;     // [n_cols]
   int64_t n_cols;
@@ -865,6 +866,11 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
         pb[b] = wperm0 + (int64_t)b * wperm_stride;
         pc[b] = (float*)nxt[b];
       }
+      // 64 gathered columns (a bond cap of 32): the stream over the rows in memory order; anything else: the tile kernel
+      if (n0 == 64 && (k == 32 || k == 64) && src->row_order && src->row_sorted != src->row_off && !getenv("NDMPS_PROJ64_TILES"))
+        NDMPS_TRY(ndmps_sgemm_gathered64_stream_batched(batch, m0, k, pa.data(), src->row_sorted, src->row_order, src->col_off,
+                                                        pb.data(), k, pc.data(), k, s));
+      else
       NDMPS_TRY(ndmps_sgemm_indexed_batched(batch, m0, k, n0, pa.data(), 0, src->row_off, src->col_off, 1, pb.data(), k,
                                             pc.data(), k, nullptr, nullptr, s));
       for (int b = 0; b < batch; ++b) {
@@ -1095,10 +1101,12 @@ extern "C" int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h
                                                 const int64_t* h_core_offsets, int64_t* h_bonds_out,
                                                 double* h_spectra, const int64_t* h_spec_offsets,
                                                 const int64_t* d_row_off, const int64_t* d_row_off_sorted,
-                                                const int64_t* d_col_off, const int32_t* d_col_perm, int64_t n_cols,
-                                                void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+                                                const int32_t* d_row_order, const int64_t* d_col_off,
+                                                const int32_t* d_col_perm, int64_t n_cols, void* d_ws, int64_t ws_bytes,
+                                                ndmps_stream_t stream) {
   NDMPS_REQUIRE(d_row_off && d_col_off && d_col_perm && n_cols >= 1, "NULL permutation table");
-  SweepSource src{d_row_off, d_row_off_sorted ? d_row_off_sorted : d_row_off, d_col_off, d_col_perm, n_cols};
+  SweepSource src{d_row_off, d_row_off_sorted ? d_row_off_sorted : d_row_off, d_row_off_sorted ? d_row_order : nullptr, d_col_off,
+                  d_col_perm, n_cols};
   return retry_without_team([&]() {
     return sweep_impl<float>(batch, (float* const*)h_volume, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets,
                              h_bonds_out, h_spectra, h_spec_offsets, d_ws, ws_bytes, stream, &src);

@@ -329,11 +329,22 @@ int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h_volume, in
                                      const int64_t* h_core_offsets, int64_t* h_bonds_out,
                                      double* h_spectra, const int64_t* h_spec_offsets,
                                      const int64_t* d_row_off, const int64_t* d_row_off_sorted,
-                                     const int64_t* d_col_off, const int32_t* d_col_perm, int64_t n_cols,
-                                     void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+                                     const int32_t* d_row_order, const int64_t* d_col_off,
+                                     const int32_t* d_col_perm, int64_t n_cols, void* d_ws, int64_t ws_bytes,
+                                     ndmps_stream_t stream);
 /* d_row_off_sorted (may be NULL): the entries of d_row_off in ascending order.  A Gram matrix is a sum over rows, so
  * its kernels may visit them in any order; in ascending order of their offsets they read the volume front to back
- * (32 x 262144 x 64: 1.14 -> 0.74 ms).  The projection keeps d_row_off (its output rows are the rows).
+ * (32 x 262144 x 64: 1.14 -> 0.74 ms).  d_row_order (may be NULL): d_row_off_sorted[s] = d_row_off[d_row_order[s]]; with
+ * it the first projection of a 64-column merged run (bond cap 32) is the stream below, its result rows scattered to
+ * their places; every other projection keeps d_row_off.
+ * ndmps_sgemm_gathered64_stream_batched: C[b] (m x n, n = 32 or 64, leading dimension ldc) = A[b] W[b] with A[b] the
+ * (m x 64) matrix h_A[b][d_row_sorted[s] + d_col_off[c]] (rows in ascending order of their offsets, columns in
+ * aligned runs of four consecutive offsets), row s of the product stored as row d_row_order[s] of C[b]. */
+int ndmps_sgemm_gathered64_stream_batched(int batch, int64_t m, int64_t n, const float* const* h_A,
+                                          const int64_t* d_row_sorted, const int32_t* d_row_order,
+                                          const int64_t* d_col_off, const float* const* h_B, int64_t ldb,
+                                          float* const* h_C, int64_t ldc, ndmps_stream_t stream);
+/* (ndmps_gram_indexed_f32:)
  * G = A^T A where element (r, c) of A is d_base[d_row_off[r] + d_col_off[c]] (wide path: n >= 64, m >= 256);
  * d_col_perm (may be NULL): entry (a, b) of the product is stored at G[d_col_perm[a]][d_col_perm[b]] -- the columns
  * were visited in the memory order of the volume, the result comes out in site order */

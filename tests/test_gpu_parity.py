@@ -1576,3 +1576,34 @@ def test_gathered_gram_stores_its_result_through_the_column_permutation(m, n, ba
         ref[np.ix_(perm, perm)] = a.T @ a
         assert np.abs(got[z] - ref).max() <= 1e-13 * np.abs(ref).max() * math.sqrt(m)
         assert np.array_equal(got[z], got[z].T)
+
+
+@pytest.mark.parametrize("m,n,batch", [(4096, 32, 3), (1000, 32, 2), (8200, 64, 2), (33, 32, 1)])
+def test_streamed_projection_of_64_gathered_columns(m, n, batch):
+    """ndmps_sgemm_gathered64_stream_batched (the first projection of a bond cap of 32 in the fused sweep): rows
+    visited in ascending order of their offsets, every result row stored at its own place; against the fp64
+    product of the gathered matrix, and bit for bit against the tile kernel on the same tables' site order."""
+    lib = _lib.load()
+    rng = np.random.default_rng(m + n + batch)
+    quads = rng.permutation(16)
+    col_off = (8 * quads[:, None] + np.arange(4)[None, :]).reshape(-1).astype(np.int64)   # aligned runs of four
+    row_off = rng.permutation(m).astype(np.int64) * 128                                    # rows 128 floats apart
+    order = np.argsort(row_off, kind="stable")
+    bases = [rng.standard_normal(m * 128).astype(np.float32) for _ in range(batch)]
+    ws_ = [rng.standard_normal((64, n)).astype(np.float32) for _ in range(batch)]
+    d_a, d_w = [dev(b) for b in bases], [dev(w) for w in ws_]
+    out = [torch.full((m, n), float("nan"), dtype=torch.float32, device=DEV) for _ in range(batch)]
+    ref_out = [torch.empty((m, n), dtype=torch.float32, device=DEV) for _ in range(batch)]
+    t_sorted, t_order, t_col, t_row = dev(row_off[order]), dev(order.astype(np.int32)), dev(col_off), dev(row_off)
+    ptrs = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    _lib.check(lib.ndmps_sgemm_gathered64_stream_batched(batch, m, n, ptrs(d_a), t_sorted.data_ptr(), t_order.data_ptr(),
+                                                         t_col.data_ptr(), ptrs(d_w), n, ptrs(out), n, sp()))
+    _lib.check(lib.ndmps_sgemm_indexed_batched(batch, m, n, 64, ptrs(d_a), 0, t_row.data_ptr(), t_col.data_ptr(), 1, ptrs(d_w), n,
+                                               ptrs(ref_out), n, None, None, sp()))
+    for z in range(batch):
+        a = bases[z][row_off[:, None] + col_off[None, :]].astype(np.float64)
+        ref = a @ ws_[z].astype(np.float64)
+        got = out[z].cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max() * 8
+        assert np.abs(got - ref_out[z].cpu().numpy()).max() <= 2e-6 * np.abs(ref).max() * 8

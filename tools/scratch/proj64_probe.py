@@ -1,5 +1,5 @@
-"""First projection of a bond cap of 32 (A = 262144 x 64 gathered from the volume, times 64 x 32): rows in site order
-against rows in memory order (output rows scattered to their places)."""
+"""First projection of a bond cap of 32 (A = 262144 x 64 gathered from the volume, times 64 x 32): the tile kernel with
+rows in site order / in memory order (output rows scattered to their places), and the stream (proj64_stream_kernel)."""
 import ctypes as C
 import os
 import sys
@@ -46,4 +46,10 @@ a = timed(lambda: _lib.check(lib.ndmps_sgemm_indexed_batched(batch, m0, k, 64, p
                                                              pb, k, pc, k, None, None, sp())))
 b = timed(lambda: _lib.check(lib.ndmps_sgemm_indexed_batched(batch, m0, k, 64, pa, 0, row_sorted.data_ptr(), col_off.data_ptr(), 1,
                                                              pb, k, pc2, k, c_rows.data_ptr(), c_cols.data_ptr(), sp())))
+out3 = [torch.empty(m0 * k, device=dev) for _ in range(batch)]
+pc3 = ptrs(out3)
+order32 = order.to(torch.int32).contiguous()
+c = timed(lambda: _lib.check(lib.ndmps_sgemm_gathered64_stream_batched(batch, m0, k, pa, row_sorted.data_ptr(), order32.data_ptr(),
+                                                                       col_off.data_ptr(), pb, k, pc3, k, sp())))
+print(f"stream {c:.3f} ms ({(4.0 * numel * batch * 1.5) / c / 1e9:.2f} TB/s read + write), max diff vs tiles {max(float((x - y).abs().max()) for x, y in zip(out[:2], out3[:2])):.1e}")
 print(f"site order {a:.3f} ms, memory order {b:.3f} ms; max diff {max(float((x - y).abs().max()) for x, y in zip(out[:2], out2[:2])):.1e}")
