@@ -228,3 +228,19 @@ def test_bench_strong_scaling_mode_world_size_2_gloo():
     assert seeds0 == list(range(2025, 2057)) and seeds1 == list(range(2057, 2089))
     assert el0 == el1 and el0 >= 2 * 0.064
     assert v0 == v1 == pytest.approx(64 * 128 ** 3 * 2 / el0 / 1e6)  # the total counted once, not per rank
+
+
+def test_group_count_follows_the_volumes_per_gpu():
+    """core/batch.default_groups: two concurrent lockstep groups from 32 volumes per GPU on, one below; the bench takes
+    it per rank when --groups is not given -- weak scaling keeps two groups of 32, BASELINE's 64 volumes in total over 8
+    GPUs run as one group of 8 per GPU -- and an explicit --groups wins."""
+    import bench
+    from imgcompressionmps_amd.core.batch import default_groups
+
+    assert [default_groups(n) for n in (1, 8, 24, 31, 32, 64, 128)] == [1, 1, 1, 1, 2, 2, 2]
+    assert bench.job_descriptor(bench.parse([]), 1)["groups"] == 2
+    assert bench.job_descriptor(bench.parse([]), 8)["groups"] == 2
+    strong = bench.job_descriptor(bench.parse(["--total-volumes", "64"]), 8)
+    assert strong["batch_per_gpu"] == 8 and strong["groups"] == 1 and strong["scaling"] == "strong"
+    assert bench.job_descriptor(bench.parse(["--total-volumes", "64"]), 2)["groups"] == 2
+    assert bench.job_descriptor(bench.parse(["--total-volumes", "64", "--groups", "4"]), 8)["groups"] == 4
