@@ -44,7 +44,10 @@ def gathered_sorted():
     gathered(row_sorted)
 
 
+only = sys.argv[4] if len(sys.argv) > 4 else None  # "sorted": that variant alone (PMC passes)
 for name, fn in (("plain", plain), ("gathered", gathered), ("sorted rows", gathered_sorted)):
+    if only and not name.startswith(only):
+        continue
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r02_pmc_summary.json from two rocprofv3 PMC passes (separate runs, --pmc FETCH_SIZE and --pmc
+"""profiles/r0N_pmc_summary.json from two rocprofv3 PMC passes (separate runs, --pmc FETCH_SIZE and --pmc
 WRITE_SIZE, --output-format csv, no tracing -- the combination gpurun allows).  Per kernel: mean KB per dispatch
 of both counters and the HBM bytes per launch bench.py reports as roofline.traffic.
 
@@ -16,9 +16,9 @@ import json
 import os
 import sys
 
-DOUBLE_FETCH = ("trd_column_kernel", "gram128_kernel")  # 16 B / lane streaming loads (double2 / float4)
+DOUBLE_FETCH = ("trd_column_kernel", "gram128_kernel", "gram64_stream_kernel", "proj64_stream_kernel")  # 16 B / lane streaming loads (double2 / float4)
 KEEP = ("gram128_kernel", "gram128_reduce_kernel", "trd_team_kernel", "trd_column_kernel", "trd_tail_kernel", "trd_invit_kernel", "trd_back_kernel", "trd_bisect_kernel",
-        "gram_wide_kernel", "encode_tiled_kernel", "decode_tiled_kernel", "gemm_kernel", "gemm_bf16_kernel")
+        "gram_wide_kernel", "gram64_stream_kernel", "proj64_stream_kernel", "tile_reduce_batched_kernel", "encode_tiled_kernel", "decode_tiled_kernel", "gemm_kernel", "gemm_bf16_kernel")
 
 
 def means(d):
