@@ -663,13 +663,14 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
       vc[k] = rv[cc].vp;
     }
     const int u0 = (j + 1) / RPI;  // tiles made of finished rows only
+    const int u_end = (n + RPI - 1) / RPI;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     // finished tiles are skipped in PAIRS (one uniform branch per pair): a basic block then holds two tiles -- eight
     // independent FMA chains, both row records in flight together.  A finished tile inside a live pair is updated like
     // the other one: its rows have v_j = 0 and are never read again (half a tile of extra work per column on average).
 #pragma unroll
     for (int g = 0; g < NT / 2; ++g) {
-      if (2 * g + 1 >= u0) {
+      if (2 * g + 1 >= u0 && 2 * g < u_end) {  // u_end: tiles of rows beyond the order hold zeros
         const RowVec ra = rv[row0 + RPI * (2 * g)], rb = rv[row0 + RPI * (2 * g + 1)];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
