@@ -91,6 +91,14 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   int xcd_team, xcd_count;  // resident launches as a 1-D grid placed team by team on the XCDs (team_place); 0: 2-D grid
   int xcd_pair;        // second workgroup of a CU: members in reverse order (early leavers beside late ones)
   double* yrow;        // [B][2][8][lda] half-storage team kernel: row sums per workgroup, by parity of the column
+  // panel-blocked reduction (orders above 512, eig_panel.inc)
+  double* pv;          // [B][n_max][kPnlNB] reflectors of the current panel, row-major
+  double* pw;          // [B][n_max][kPnlNB] their companions w
+  double* ypart;       // [B][pnl_blocks_max][lda] tile partials of A v, slot = the other block index
+  double* spart;       // [B][pnl_tiles_max] tile partials of v^T A v
+  double* ucol;        // [B][2][lda] the next column, un-normalised, by parity of the column
+  double* napart;      // [B][2][pnl_blocks_max][kPnlNa] per workgroup of pnl_vec_kernel: partial norm, W^T u, V^T u
+  int pnl_blocks_max, pnl_tiles_max;
   long long* stamps;   // [B][16] wall-clock (100 MHz) marks of the single-workgroup kernels' phases (tools/trd_probe.py)
   int n_max, lda, kp;
 };
@@ -2132,6 +2140,7 @@ __global__ void trd_clear_status_kernel(TrdDesc* __restrict__ desc, int batch, T
 
 #include "eig_band.inc"
 #include "eig_sym.inc"
+#include "eig_panel.inc"
 
 // Test hook (ndmps_debug_inject_team_abort): what an aborted team launch leaves behind, without the 3 s wait
 __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
@@ -2143,6 +2152,7 @@ __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
 struct TrdLayout {
   int64_t n_max, lda, kp;
   int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
+  int64_t off_pv, off_pw, off_ypart, off_spart, off_ucol, off_napart, pnl_blocks, pnl_tiles;
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -2183,6 +2193,16 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.q_stride = band_ok ? n_max * (n_max + 2 * kBandMax) : 0;
   l.off_qlog = take(batch * l.q_stride * 8);
   l.off_yrow = take(band_ok ? batch * 2 * 8 * l.lda * 8 : 0);
+  // panel-blocked reduction (orders above 512, eig_panel.inc)
+  const bool panel_ok = n_max > 512;
+  l.pnl_blocks = ndmps::ceil_div(n_max, kPnlTB);
+  l.pnl_tiles = l.pnl_blocks * (l.pnl_blocks + 1) / 2;
+  l.off_pv = take(panel_ok ? batch * n_max * kPnlNB * 8 : 0);
+  l.off_pw = take(panel_ok ? batch * n_max * kPnlNB * 8 : 0);
+  l.off_ypart = take(panel_ok ? batch * l.pnl_blocks * l.lda * 8 : 0);
+  l.off_spart = take(panel_ok ? batch * l.pnl_tiles * 8 : 0);
+  l.off_ucol = take(panel_ok ? batch * 2 * l.lda * 8 : 0);
+  l.off_napart = take(panel_ok ? batch * 2 * l.pnl_blocks * kPnlNa * 8 : 0);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -2214,6 +2234,14 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.qlog = (double*)(base + l.off_qlog);
   w.q_stride = l.q_stride;
   w.yrow = (double*)(base + l.off_yrow);
+  w.pv = (double*)(base + l.off_pv);
+  w.pw = (double*)(base + l.off_pw);
+  w.ypart = (double*)(base + l.off_ypart);
+  w.spart = (double*)(base + l.off_spart);
+  w.ucol = (double*)(base + l.off_ucol);
+  w.napart = (double*)(base + l.off_napart);
+  w.pnl_blocks_max = (int)l.pnl_blocks;
+  w.pnl_tiles_max = (int)l.pnl_tiles;
   w.tail_lower = 0;
   w.xcd_team = w.xcd_count = w.xcd_pair = 0;
   w.n_max = (int)l.n_max;
@@ -2311,6 +2339,116 @@ int trd_check_sizes(int batch, const int64_t* h_n, int64_t& n_max) {
   for (int b = 0; b < batch; ++b) {
     NDMPS_REQUIRE(h_n[b] >= 1 && h_n[b] <= kMaxN, "eigen size n=%lld outside [1, %d]", (long long)h_n[b], kMaxN);
     n_max = std::max(n_max, h_n[b]);
+  }
+  return NDMPS_OK;
+}
+
+// Smallest order that takes the panel-blocked reduction.  A dependent launch costs ~5 us here whatever it does: two of
+// them per column (10.7 us at any order) beat the column launch -- one launch, but the trailing matrix read and
+// written, 7.6 us per column at order 1024, 13.5 at 2048, 35 at 4096 -- from about order 1500 on
+// (profiles/r04_f_panel_probe.txt: 9.6 vs 6.8 ms at 1024, 22.2 vs 26.2 at 2048, 63 vs 140 at 4096).
+int64_t panel_min_order() {
+  const char* e = getenv("NDMPS_TRD_PANEL_MIN");
+  const int64_t v = e ? atoll(e) : 1536;
+  return std::max<int64_t>(v, 513);  // the workspace holds the panel arrays from order 513 on
+}
+
+// ---- launch sequence of the panel-blocked reduction, eager or as a cached graph
+struct PnlLaunch {
+  int kind;  // 0 pnl_vec_kernel, 1 pnl_update_kernel, 2 pnl_symv_kernel
+  unsigned grid_x;
+  int j;
+};
+struct PnlGraph {
+  int dev;
+  const void* desc;  // the descriptors live in the caller's workspace: workspace address, layout and sizes name a graph
+  const void* a;
+  int64_t n_max;
+  int batch;
+  std::vector<int64_t> sizes;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  uint64_t used;
+};
+constexpr size_t kPnlGraphs = 8;  // least recently used beyond that is destroyed
+
+int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, int64_t n_max, TrdDesc* desc, const TrdWork& w,
+            hipStream_t s) {
+  const unsigned B = (unsigned)batch;
+  void (*const vec)(const TrdDesc*, TrdWork, int, int) =
+      n_max <= 1024 ? pnl_vec_kernel<4> : (n_max <= 2048 ? pnl_vec_kernel<8> : pnl_vec_kernel<16>);
+  void (*const kernels[3])(const TrdDesc*, TrdWork, int, int) = {vec, pnl_update_kernel, pnl_symv_kernel};
+  int n_uniform = (int)h_n[0];  // equal orders: the kernels take the order from their arguments
+  for (int b = 1; b < batch; ++b)
+    if (h_n[b] != h_n[0]) n_uniform = 0;
+  if (getenv("NDMPS_TRD_PANEL_EAGER")) {
+    for (const PnlLaunch& q : seq)
+      hipLaunchKernelGGL(kernels[q.kind], dim3(q.grid_x, B), dim3(256), 0, s, (const TrdDesc*)desc, w, q.j, n_uniform);
+    NDMPS_LAUNCH_CHECK();
+    return NDMPS_OK;
+  }
+  static std::mutex mu;
+  static std::vector<PnlGraph> cache;
+  static uint64_t clock = 0;
+  int dev = 0;
+  NDMPS_CHECK_HIP(hipGetDevice(&dev));
+  hipGraphExec_t exec = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (PnlGraph& g : cache)
+      if (g.dev == dev && g.desc == desc && g.a == w.A && g.n_max == w.n_max && g.batch == batch &&
+          std::equal(g.sizes.begin(), g.sizes.end(), h_n)) {
+        g.used = ++clock;
+        exec = g.exec;
+        break;
+      }
+    if (!exec) {
+      PnlGraph g;
+      g.dev = dev, g.desc = desc, g.a = w.A, g.n_max = w.n_max, g.batch = batch;
+      g.sizes.assign(h_n, h_n + batch);
+      NDMPS_CHECK_HIP(hipGraphCreate(&g.graph, 0));
+      hipGraphNode_t prev = nullptr;
+      for (const PnlLaunch& q : seq) {
+        const TrdDesc* d_arg = desc;
+        TrdWork w_arg = w;
+        int j_arg = q.j, n_arg = n_uniform;
+        void* args[4] = {&d_arg, &w_arg, &j_arg, &n_arg};
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        kp.func = reinterpret_cast<void*>(kernels[q.kind]);
+        kp.gridDim = dim3(q.grid_x, B);
+        kp.blockDim = dim3(256);
+        kp.sharedMemBytes = 0;
+        kp.kernelParams = args;
+        hipGraphNode_t node = nullptr;
+        const hipError_t e = hipGraphAddKernelNode(&node, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+        if (e != hipSuccess) {
+          (void)hipGraphDestroy(g.graph);
+          ndmps::set_error("hipGraphAddKernelNode failed: %s", hipGetErrorString(e));
+          return NDMPS_EHIP;
+        }
+        prev = node;
+      }
+      const hipError_t e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) {
+        (void)hipGraphDestroy(g.graph);
+        ndmps::set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return NDMPS_EHIP;
+      }
+      g.used = ++clock;
+      if (cache.size() >= kPnlGraphs) {
+        size_t oldest = 0;
+        for (size_t i = 1; i < cache.size(); ++i)
+          if (cache[i].used < cache[oldest].used) oldest = i;
+        (void)hipDeviceSynchronize();  // rare (more than kPnlGraphs workspaces in use): its last replay may still run
+        (void)hipGraphExecDestroy(cache[oldest].exec);
+        (void)hipGraphDestroy(cache[oldest].graph);
+        cache.erase(cache.begin() + (long)oldest);
+      }
+      exec = g.exec;
+      cache.push_back(std::move(g));
+    }
+    NDMPS_CHECK_HIP(hipGraphLaunch(exec, s));  // under the lock: an entry is never destroyed between look-up and launch
   }
   return NDMPS_OK;
 }
@@ -2432,6 +2570,36 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
     // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
     for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
     ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, span_bytes);
+  } else if (n_max >= panel_min_order() && !getenv("NDMPS_TRD_NO_PANEL")) {
+    // panel-blocked reduction (eig_panel.inc): two launches per column, one update per panel of kPnlNB columns
+    w.tail_lower = 1;
+    NDMPS_CHECK_HIP(hipMemsetAsync(w.Vh, 0, (size_t)batch * n_max * l.lda * 8, s));
+    NDMPS_CHECK_HIP(hipMemsetAsync(w.pv, 0, (size_t)batch * n_max * kPnlNB * 8, s));
+    NDMPS_CHECK_HIP(hipMemsetAsync(w.pw, 0, (size_t)batch * n_max * kPnlNB * 8, s));
+    const int J_max = (int)n_max - kTail;
+    std::vector<char> ends((size_t)J_max + 1, 0);
+    for (int b = 0; b < batch; ++b) ends[(size_t)std::max<int64_t>(h_n[b] - kTail, 0)] = 1;
+    const int nbm = (int)l.pnl_blocks;
+    auto tiles = [&](int first_col) {
+      const int nblk = nbm - first_col / kPnlTB;
+      return (unsigned)(nblk * (nblk + 1) / 2);
+    };
+    // the launch sequence: (kernel, grid.x, column); replayed from a cached graph unless NDMPS_TRD_PANEL_EAGER is set
+    // (the host enqueues ~3.5 us per launch; the graph leaves the kernel boundaries)
+    std::vector<PnlLaunch> seq;
+    seq.reserve((size_t)2 * J_max + J_max / kPnlNB + 4);
+    for (int j = 0; j <= J_max; ++j) {
+      seq.push_back({0, (unsigned)(nbm - j / kPnlTB), j});
+      if (j >= 1 && (j % kPnlNB == 0 || ends[(size_t)j])) seq.push_back({1, tiles(j), j});
+      if (j < J_max) seq.push_back({2, tiles(j + 1), j});
+      if (span)
+        for (int b = 0; b < batch; ++b)
+          if (j < h_n[b] - kTail) span_bytes += 4 * (h_n[b] - j - 1) * (h_n[b] - j - 1);  // the lower half, read once
+    }
+    NDMPS_TRY(pnl_run(seq, batch, h_n, n_max, desc, w, s));
+    // nothing is pending when the tail kernel takes over: its update of "the last column launch" must vanish
+    NDMPS_CHECK_HIP(hipMemsetAsync(w.y, 0, (size_t)batch * 2 * l.lda * 8, s));
+    ndmps::span_end(span, s, ndmps::kSpanTridiagColumns, 2 * (int64_t)std::max(J_max, 0), span_bytes);
   } else {
     for (int j = 0; j < n_max - kTail; ++j) {
       hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);

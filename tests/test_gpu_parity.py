@@ -780,6 +780,67 @@ def test_topk_solver_orders_above_512_in_mixed_batches():
             _check_topk(g, w, v, k, k_max=128)
 
 
+@pytest.mark.parametrize("n", [640, 1537, 3000, 4096])
+def test_topk_solver_panel_blocked_reduction(n, monkeypatch):
+    """Orders from 1536 on (here: from 513 on, NDMPS_TRD_PANEL_MIN) are reduced panel by panel (csrc/eig_panel.inc: two launches per column on the lower tiles, one
+    MFMA update per 32 columns): orders that are no multiple of the 64-wide tiles or of the panel width, the largest
+    order the solver takes, 128 vectors."""
+    lib = _lib.load()
+    monkeypatch.setenv("NDMPS_TRD_PANEL_MIN", "513")
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n + 5, n)) * np.logspace(0, -5, n)[None, :]
+    g = a.T @ a
+    (w, v), = _topk(lib, [g], [128])
+    _check_topk(g, w, v, 128)
+
+
+def test_topk_solver_panel_blocked_reduction_degenerate_spectra(monkeypatch):
+    """The panel path on matrices whose reflectors vanish or whose spectra are multiple: zero, identity, rank one,
+    exact multiplicities, diagonal, decoupled identical blocks, orders 600 .. 700 in ONE batch (mixed orders: the
+    kernels read the order from the descriptors)."""
+    lib = _lib.load()
+    monkeypatch.setenv("NDMPS_TRD_PANEL_MIN", "513")
+    rng = np.random.default_rng(2)
+    n = 600
+    u = rng.standard_normal(n)
+    q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    lam = np.r_[np.full(10, 5.0), np.full(20, 1.0), np.zeros(n - 30)]
+    blk = rng.standard_normal((70, 70))
+    cases = [(np.zeros((n, n)), 8), (np.eye(n), 8), (np.outer(u, u), 8), ((q * lam) @ q.T, 30),
+             (np.diag(np.arange(n, 0, -1.0)), 10), (np.kron(np.eye(10), blk @ blk.T), 40), (np.eye(650) * 3.0, 50)]
+    mats = [0.5 * (g + g.T) for g, _ in cases]
+    for g, k, (w, v) in zip(mats, [k for _, k in cases], _topk(lib, mats, [k for _, k in cases])):
+        _check_topk(g, w, v, k, tol_scale=4.0, k_max=50)
+
+
+def test_topk_solver_panel_path_against_the_column_launches(monkeypatch):
+    """The same matrices through the panel-blocked reduction, its launches issued one by one instead of replayed from
+    the cached graph (bit-identical: same kernels in the same order), and through the one-launch-per-column reduction
+    it replaces above order 512 (same eigenvalues, same kept subspace)."""
+    lib = _lib.load()
+    monkeypatch.setenv("NDMPS_TRD_PANEL_MIN", "513")
+    rng = np.random.default_rng(3)
+    mats = []
+    for n in (1100, 777):
+        a = rng.standard_normal((n + 64, n)) * np.logspace(0, -5, n)[None, :]
+        mats.append(a.T @ a)
+    ks = [96, 64]
+    first = _topk(lib, mats, ks, k_max=128)
+    again = _topk(lib, mats, ks, k_max=128)  # replayed from the cached graph if the workspace came back at the same address
+    monkeypatch.setenv("NDMPS_TRD_PANEL_EAGER", "1")
+    eager = _topk(lib, mats, ks, k_max=128)
+    monkeypatch.delenv("NDMPS_TRD_PANEL_EAGER")
+    monkeypatch.setenv("NDMPS_TRD_NO_PANEL", "1")
+    columns = _topk(lib, mats, ks, k_max=128)
+    for g, k, (w, v), (w1, v1), (w2, v2), (w3, v3) in zip(mats, ks, first, again, eager, columns):
+        assert np.array_equal(w, w1) and np.array_equal(v, v1)
+        assert np.array_equal(w, w2) and np.array_equal(v, v2)
+        _check_topk(g, w3, v3, k, k_max=128)
+        assert np.abs(w - w3).max() <= 1e-13 * w[0]
+        gap = (w[k - 1] - w[k]) / w[0] if k < 128 else 1.0
+        assert np.abs(v @ v.T - v3 @ v3.T).max() <= 50 * 2.2e-16 / max(gap, 1e-300) + 1e-11
+
+
 def test_topk_solver_volume_gram_matrices_with_noise_floor_clusters():
     """The matrices the sweep meets: Gram matrices of the chi-capped unfoldings of a noisy volume, a few large
     eigenvalues over a floor of ~n near-equal ones (gaps ~1e-9 of the largest).  The kept subspace must agree
