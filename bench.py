@@ -72,6 +72,8 @@ def parse(argv=None):
                          "volumes of a group are encoded in lockstep (0 / not given: two from 32 volumes per GPU on, else one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="profiling aid: the timed loop only")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="the default line carries short runs of BASELINE configs 2 .. 5 (`configs`); this leaves them out")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses N ranks on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
@@ -180,7 +182,7 @@ def pmc_traffic(kernel_key):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/r0*_pmc_summary.json, written
     by tools/pmc_to_json.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; the newest round that has the kernel),
     or None."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 entry = json.load(f)[kernel_key]
@@ -191,16 +193,24 @@ def pmc_traffic(kernel_key):
 
 
 # ------------------------------------------------------------------------------------------ launch spans
-SLOT_COLUMNS, SLOT_TEAM, SLOT_GRAM, SLOT_GRAM_SMALL = 1, 2, 3, 4
+SLOT_COLUMNS, SLOT_TEAM, SLOT_GRAM, SLOT_GRAM_SMALL, SLOT_PANEL, SLOT_TAIL, SLOT_VECTORS = 1, 2, 3, 4, 5, 6, 7
 SLOT_INFO = {
-    SLOT_COLUMNS: ("trd_column_kernel (one launch per column of the Householder tridiagonalisation, orders above 512: "
+    SLOT_COLUMNS: ("trd_column_kernel (one launch per column of the Householder tridiagonalisation, orders 513 .. 1535: "
                    "the trailing matrices read and written once per launch)", "hbm"),
     SLOT_TEAM: ("trd_team_kernel (register-resident Householder tridiagonalisation of a lockstep group's matrices, one "
-                "launch for all columns; latency-bound: one exchange between the workgroups of a matrix per column)", "hbm"),
+                "launch for all columns; latency-bound: one exchange between the workgroups of a matrix per column)", "latency"),
     SLOT_GRAM: ("gram128_kernel, the launches that fill the GPU for milliseconds and take the device-side turn (fp64 Gram "
                 "matrices A^T A of a lockstep group's raw unfoldings in one launch, v_mfma_f64_16x16x4_f64)", "mfma"),
     SLOT_GRAM_SMALL: ("gram128_kernel / gram_wide_kernel, the Gram launches of the later sites (fp64 MFMA)", "mfma"),
+    SLOT_PANEL: ("pnl_vec_kernel + pnl_symv_kernel + pnl_update_kernel (panel-blocked Householder tridiagonalisation, orders "
+                 "from 1536 on: two dependent launches per column, the lower tiles of the trailing matrix read once per "
+                 "column; each launch costs ~5 us whatever it moves)", "hbm"),
+    SLOT_TAIL: ("trd_tail_kernel + trd_bisect_kernel (last 128 columns of the reduction in LDS, eigenvalues by "
+                "65-section: one or a few workgroups per matrix)", "latency"),
+    SLOT_VECTORS: ("trd_invit_kernel + trd_ortho_*_kernel + trd_wy_kernel + trd_back_kernel (eigenvectors of T by inverse "
+                   "iteration, Cholesky-QR, back-transformation: one or a few workgroups per matrix)", "latency"),
 }
+BOUNDED_SLOTS = (SLOT_COLUMNS, SLOT_GRAM, SLOT_GRAM_SMALL, SLOT_PANEL)
 
 
 def collect_slots(lib):
@@ -216,12 +226,15 @@ def collect_slots(lib):
     return out
 
 
-def roofline_of(slots, steps):
-    """The roofline object: the instrumented kernel with the most device time in the timed region (HIP events on the
-    launching streams around every launch, csrc/util.hip) among those a roofline bounds -- the MFMA-bound Gram launches
-    and the HBM-bound column launches.  The resident tridiagonalisation is LATENCY-bound (one exchange between the
-    workgroups of a matrix per column, no trailing-matrix traffic): its span is reported next to the roofline
-    (`tridiagonalisation`), with its share of device time, and named as the larger one where it is."""
+def roofline_of(slots, steps, eig_order=None):
+    """The roofline object.  `roofline` itself prices the instrumented kernel with the most device time in the timed
+    region (HIP events on the launching streams around every launch, csrc/util.hip) AMONG THOSE A ROOFLINE BOUNDS -- the
+    MFMA-bound Gram launches, the HBM-bound column / panel launches.  `dominant` names the instrumented kernel class
+    with the most device time OF ALL, whatever bounds it: in the batch configurations that is the latency-bound resident
+    tridiagonalisation, priced against HBM (2 x 8 n^2 bytes per matrix: the matrix in, the reflectors out) and against
+    the fp64 vector peak (4/3 n^3 flops per matrix) so that its distance from any roofline is a number.  The
+    end-to-end figure SURVEY 8(d) names as the headline, 2 s N / t_total, is `end_to_end_frac` (filled in by the
+    caller)."""
     busy = {s: v for s, v in slots.items() if v[1] > 0}
 
     def line(slot):
@@ -229,15 +242,25 @@ def roofline_of(slots, steps):
         name, bound = SLOT_INFO[slot]
         per_us = ms * 1e3 / launches
         per_amount = amount / launches
+        out = {"kernel": name, "bound": bound, "launch_us": per_us, "launches_per_step": launches / steps,
+               "device_ms_per_step": ms / steps}
         if bound == "mfma":
-            achieved, peak, unit = per_amount / (per_us * 1e-6) / 1e12, F64_MFMA_PEAK_TFLOPS, "TFLOP/s"
-        else:
-            achieved, peak, unit = per_amount / (per_us * 1e-6) / 1e9, HBM_PEAK_GBPS, "GB/s"
-        return {"kernel": name, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                ("flops_per_launch" if bound == "mfma" else "algorithmic_bytes_per_launch"): per_amount,
-                "launch_us": per_us, "launches_per_step": launches / steps, "device_ms_per_step": ms / steps}
+            achieved = per_amount / (per_us * 1e-6) / 1e12
+            out.update({"achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
+                        "flops_per_launch": per_amount})
+        elif amount > 0:
+            achieved = per_amount / (per_us * 1e-6) / 1e9
+            out.update({"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_launch": per_amount})
+        if slot == SLOT_TEAM:
+            out["bound"] = "latency of the per-column exchange (no trailing-matrix traffic; priced against HBM and fp64 for scale)"
+            out["span_covers"] = "the launch and its wait for the device-side turn"
+            if eig_order:
+                flops = per_amount / 16.0 * (4.0 / 3.0) * eig_order  # bytes = 16 n^2 per matrix
+                out["fp64_vector_frac"] = flops / (per_us * 1e-6) / 1e12 / F64_MFMA_PEAK_TFLOPS
+        return out
 
-    bounded = {s: v for s, v in busy.items() if s != SLOT_TEAM}
+    bounded = {s: v for s, v in busy.items() if s in BOUNDED_SLOTS}
     if not bounded:
         roof = {"kernel": None, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
                 "note": "no MFMA- or HBM-bound instrumented kernel ran in the timed region"}
@@ -252,14 +275,47 @@ def roofline_of(slots, steps):
     if dom in (SLOT_GRAM, SLOT_GRAM_SMALL):
         roof["peak_source"] = ("AMD MI355X spec, FP64 matrix 78.6 TFLOP/s = 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz; "
                                "77.7 measured with tools/scratch/mfma_f64_rate.hip (MI355X_MICROARCH.md lists no f64 row)")
-    roof["other_instrumented_kernels"] = [line(s) for s in sorted(bounded) if s != dom]
+    roof["other_instrumented_kernels"] = [line(s) for s in sorted(busy) if s != dom]
+    if busy:
+        top = max(busy, key=lambda s: busy[s][0])
+        d = line(top)
+        d["is_the_roofline_kernel"] = bool(top == dom)
+        d["share_of_instrumented_device_time"] = busy[top][0] / sum(v[0] for v in busy.values())
+        d["note"] = ("the instrumented kernel class with the most device time in the timed region; spans of different "
+                     "streams overlap, so the shares are of summed span time, not of the step")
+        roof["dominant"] = d
     if SLOT_TEAM in busy:
         t = line(SLOT_TEAM)
-        t["bound"] = "latency of the per-column exchange (no roofline applies: 2 x 8 n^2 bytes per matrix over the launch)"
-        t["span_covers"] = "the launch and its wait for the device-side turn"
         t["larger_than_the_roofline_kernel"] = bool(dom is None or busy[SLOT_TEAM][0] > busy[dom][0])
         roof["tridiagonalisation"] = t
     return roof
+
+
+class ProfiledRegion:
+    """rocprofv3 --selected-regions collects only between roctxProfilerResume and roctxProfilerPause: the timed loop
+    brackets itself, so the committed kernel summaries list the timed region and not the volume generator or the
+    reference points behind it.  Without the profiler (or its library) the calls do nothing."""
+
+    def __init__(self):
+        import ctypes as C
+
+        self.lib = None
+        for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+            try:
+                self.lib = C.CDLL(name)
+                self.lib.roctxProfilerResume.argtypes = [C.c_uint64]
+                self.lib.roctxProfilerPause.argtypes = [C.c_uint64]
+                break
+            except (OSError, AttributeError):
+                self.lib = None
+
+    def resume(self):
+        if self.lib is not None:
+            self.lib.roctxProfilerResume(0)
+
+    def pause(self):
+        if self.lib is not None:
+            self.lib.roctxProfilerPause(0)
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -310,10 +366,49 @@ def main():
            "dist": dist, "NDMPS": NDMPS, "_lib": _lib, "batch_mod": batch_mod, "ndmps_mod": ndmps_mod,
            "barrier": barrier, "reduce_max": reduce_max}
     line = run_tensor(ctx) if job["kind"] == "tensor" else run_cubes(ctx)
+    if (rank == 0 and world == 1 and job["config"] == "metric" and not args_overridden(args) and not args.skip_single
+            and not args.no_configs):
+        line["configs"] = other_configs(ctx)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_configs(ctx):
+    """Short runs (3 steps behind 1 warm-up step) of BASELINE configs 2 .. 5 at their full sizes, in the same process and
+    inside whatever clock is put around it: ms per step, throughput, the end-to-end fraction of the HBM roofline and the
+    dominant instrumented kernel of each.  `python bench.py --config N` gives the full line of one of them."""
+    import copy
+    import gc
+
+    torch = ctx["torch"]
+    out = {}
+    for name in ("2", "3", "4", "5"):
+        a2 = copy.copy(ctx["args"])
+        cfg = CONFIGS[name]
+        a2.config, a2.kind = name, cfg["kind"]
+        for key in ("size", "chi", "mode", "batch", "groups", "total_volumes"):
+            setattr(a2, key, cfg[key])
+        a2.shape = tuple(cfg.get("shape", (cfg["size"],) * 3))
+        a2.steps, a2.warmup, a2.skip_single, a2.no_cpu_baseline = 3, 1, True, True
+        c2 = dict(ctx, args=a2, job=job_descriptor(a2, 1))
+        t0 = time.perf_counter()
+        full = run_tensor(c2) if cfg["kind"] == "tensor" else run_cubes(c2)
+        roof = full["roofline"]
+        dom = roof.get("dominant") or {}
+        out[name] = {"workload": full["config"]["workload"], "scaling": full["scaling"], "dtype": full["dtype"],
+                     "steps": a2.steps, "warmup": a2.warmup, "ms_per_step": full["ms_per_step"], "Mvoxels_per_s": full["value"],
+                     "end_to_end_frac": roof.get("end_to_end_frac"), "bonds": full["config"].get("bonds"),
+                     "roofline_kernel": {k: roof.get(k) for k in ("kernel", "bound", "frac", "device_ms_per_step")},
+                     "dominant": {k: dom.get(k) for k in ("kernel", "bound", "frac", "device_ms_per_step",
+                                                           "share_of_instrumented_device_time")},
+                     "team_fallbacks": full.get("team_fallbacks"), "wall_s_with_setup": None}
+        del full, c2
+        gc.collect()
+        torch.cuda.empty_cache()
+        out[name]["wall_s_with_setup"] = time.perf_counter() - t0
+    return out
 
 
 def base_line(job, args, world, value, ms_per_step, dtype, workload, extra_config):
@@ -410,12 +505,16 @@ def run_cubes(ctx):
         return o, o.to_tensor(as_torch=True)
 
     timer = ndmps_mod.StageTimer()
+    region = ProfiledRegion()
 
     def start_profiling():
         ndmps_mod.set_stage_timer(timer)
         _lib.check(lib.ndmps_profile_enable(1))
+        torch.cuda.synchronize()
+        region.resume()
 
     elapsed = timed_steps(step, args.steps, args.warmup, ctx["barrier"], ctx["reduce_max"], after_warmup=start_profiling)
+    region.pause()
     ndmps_mod.set_stage_timer(None)
     _lib.check(lib.ndmps_profile_enable(0))
     obj, rec = last["obj"], last["rec"]
@@ -423,7 +522,7 @@ def run_cubes(ctx):
               for k, v in timer.totals_ms().items()}
     value = throughput(job, n_vox, args.steps, elapsed)
     ms_per_step = elapsed / args.steps * 1e3
-    roofline = roofline_of(collect_slots(lib), args.steps)
+    roofline = roofline_of(collect_slots(lib), args.steps, eig_order=min(8 * job["chi"], 512))
     algo_bytes = 2 * 4 * n_vox  # read the volume once, write the reconstruction once
     roofline["end_to_end_algorithmic_GBps"] = len(xs) * algo_bytes / (ms_per_step * 1e-3) / 1e9
     roofline["end_to_end_frac"] = roofline["end_to_end_algorithmic_GBps"] / HBM_PEAK_GBPS
@@ -653,10 +752,15 @@ def run_tensor(ctx):
 
         dtype, storage = "f32", "fp32 storage, rows of the unfoldings sharded over the ranks (core/sharded.py)"
 
+    region = ProfiledRegion()
+
     def start_profiling():
         _lib.check(lib.ndmps_profile_enable(1))
+        torch.cuda.synchronize()
+        region.resume()
 
     elapsed = timed_steps(step, args.steps, args.warmup, ctx["barrier"], ctx["reduce_max"], after_warmup=start_profiling)
+    region.pause()
     _lib.check(lib.ndmps_profile_enable(0))
     value = n_vox * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3

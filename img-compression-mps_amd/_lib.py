@@ -127,6 +127,8 @@ SIGNATURES = {
                                     vp, i64, vp]),
     "ndmps_ssim_workspace_bytes": (i64, [C.c_int, p_i64]),
     "ndmps_ssim_f32": (C.c_int, [vp, vp, C.c_int, p_i64, p_f64, vp, i64, vp]),
+    "ndmps_ssim_slices_workspace_bytes": (i64, [p_i64, C.c_int]),
+    "ndmps_ssim_slices_f32": (C.c_int, [vp, vp, p_i64, C.c_int, p_f64, vp, i64, vp]),
     "ndmps_psnr_workspace_bytes": (i64, []),
     "ndmps_psnr_f32": (C.c_int, [vp, vp, i64, p_f64, vp, i64, vp]),
     "ndmps_quantize_f32": (C.c_int, [vp, i64, C.c_float, C.c_float, C.c_int, vp, vp]),

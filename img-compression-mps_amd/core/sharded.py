@@ -31,17 +31,31 @@ from .mps import DeviceMPS
 _CUTOFF_FLOOR = 1e-6  # csrc/tt.hip kCutoffFloor: fp32 data
 
 
-def _kept(sigma, cutoff, max_bond):
-    c = max(float(cutoff), _CUTOFF_FLOOR)
-    k = int(np.count_nonzero(sigma > c * sigma[0]))
-    return max(1, min(k, int(max_bond), len(sigma)))
+def _all_max(flag: int, device, world, group) -> int:
+    """The largest of the ranks' flags (a collective every rank joins; world size 1: the flag itself)."""
+    import torch
+    import torch.distributed as dist
+
+    if world <= 1:
+        return int(flag)
+    t = torch.tensor([int(flag)], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
 
 
 def from_dense_sharded(local_dense, dims, max_bond, cutoff: float = 1e-10, group=None) -> DeviceMPS:
     """``local_dense``: this rank's rows of the site-order tensor, a device fp32 tensor of
     ``prod(dims) / world`` elements (rank r holds rows ``[r, r + 1) * prod(dims) / world`` of the flattened tensor;
     ``world`` must divide ``dims[0]``).  ``dims``: the site dimensions of the FULL tensor.  Returns the MPS of the full
-    tensor, replicated on every rank.  ``local_dense`` is left untouched."""
+    tensor, replicated on every rank.  ``local_dense`` is left untouched.
+
+    Per sharded site: ONE collective on the data path (the all-reduce of the Gram matrix) and no host read -- the rank
+    is decided on the device from the eigenvalues, as in the single-GPU sweep (cores and carried matrices keep their
+    cap shapes, zero beyond the rank; the ranks come back in one copy behind the loop).  Only sites whose
+    eigenproblem may take the resident tridiagonalisation (orders 129 .. 512) add a one-word all-reduce and one host
+    read: a launch that gave up on ANY rank sends EVERY rank to the column launches for that site (the two routes
+    differ in the last bits and the ranks must keep identical cores).  Every decision that leads to a collective or
+    to an exception is itself taken collectively."""
     import torch
     import torch.distributed as dist
 
@@ -60,69 +74,80 @@ def from_dense_sharded(local_dense, dims, max_bond, cutoff: float = 1e-10, group
         raise ValueError("local_dense must be this rank's prod(dims) / world fp32 elements on the device")
     device = local_dense.device
     stream = _lib.stream_ptr()
+    max_n = int(lib.ndmps_syevd_topk_max_n())
+    # ---- the sharded sites, known up front: the shapes follow the caps, not the ranks
+    sites, chi_r, i = [], 1, L - 1
+    while i >= 1:
+        n = dims[i] * chi_r
+        rows_local = int(np.prod(dims[:i], dtype=np.int64)) // world
+        # sharded while the unfolding is tall on every rank and the eigenproblem fits the direct solver
+        if rows_local < max(n, 256) or n > max_n:
+            break
+        sites.append((i, n, rows_local, chi_r, min(chi, n)))
+        chi_r, i = min(chi, n), i - 1
+    i_head = i
     cores = [None] * L
-    carried = local_dense.reshape(-1)          # (rows_local, n_i) row-major, rows_local = rows_global / world
-    chi_r = 1
-    i = L - 1
+    cut = max(float(cutoff), _CUTOFF_FLOOR)
     with torch.cuda.device(device):
-        while i >= 1:
-            n = dims[i] * chi_r
-            rows_global = int(np.prod(dims[:i], dtype=np.int64))
-            rows_local = rows_global // world
-            # sharded while the unfolding is tall on every rank and the eigenproblem fits the direct solver
-            if rows_local < max(n, 256) or n > int(lib.ndmps_syevd_topk_max_n()):
-                break
+        # ---- one arena for every site
+        n_big = max([s[1] for s in sites], default=1)
+        g = torch.empty(n_big * n_big, dtype=torch.float64, device=device)
+        v = torch.empty(n_big * n_big, dtype=torch.float64, device=device)
+        w = torch.empty(n_big, dtype=torch.float64, device=device)
+        gbytes = max([int(lib.ndmps_gram_workspace_bytes(s[2], s[1])) for s in sites], default=0)
+        ebytes = max([int(lib.ndmps_syevd_topk_workspace_bytes(s[1], 1, s[4])) for s in sites], default=0)
+        gws = torch.empty(max(gbytes, 1), dtype=torch.uint8, device=device)
+        ews = torch.empty(max(ebytes, 1), dtype=torch.uint8, device=device)
+        pong = [torch.empty(max([s[2] * s[4] for s in sites[k::2]], default=1), dtype=torch.float32, device=device)
+                for k in range(2)]
+        ranks_dev = torch.zeros(max(len(sites), 1), dtype=torch.int32, device=device)
+        status_dev = torch.zeros(max(len(sites), 1), dtype=torch.int32, device=device)
+        carried = local_dense.reshape(-1)          # (rows_local, n_i) row-major, rows_local = rows_global / world
+        for t, (i, n, rows_local, chi_r, k_cap) in enumerate(sites):
             a = carried
-            g = torch.empty((n, n), dtype=torch.float64, device=device)
-            nbytes = int(lib.ndmps_gram_workspace_bytes(rows_local, n))
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            _lib.check(lib.ndmps_gram_f32(a.data_ptr(), rows_local, n, n, g.data_ptr(), ws.data_ptr(), nbytes, stream))
+            gm = g[: n * n]
+            _lib.check(lib.ndmps_gram_f32(a.data_ptr(), rows_local, n, n, gm.data_ptr(), gws.data_ptr(), gbytes, stream))
             if world > 1:
-                dist.all_reduce(g, group=group)  # the exchange step: Gram matrices of the row blocks add up
-            k_max = min(chi, n)
-            v = torch.empty((n, n), dtype=torch.float64, device=device)
-            w = torch.empty(n, dtype=torch.float64, device=device)
-            ebytes = int(lib.ndmps_syevd_topk_workspace_bytes(n, 1, k_max))
-            ews = torch.empty(ebytes, dtype=torch.uint8, device=device)
+                dist.all_reduce(gm, group=group)  # the exchange step: Gram matrices of the row blocks add up
             sizes = _lib.i64_array([n])
-            def values():
-                _lib.check(lib.ndmps_syevd_topk_values_f64(1, g.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(), n,
-                                                           k_max, ews.data_ptr(), ebytes, stream))
 
-            values()
-            # the host reads the eigenvalues next: a resident tridiagonalisation that gave up is redone on the column
-            # launches here.  The two routes differ in the last bits, and the ranks must keep identical cores, so a
-            # recovery on any rank makes every rank take the column launches for this site.
-            recovered = C.c_int(0)
-            _lib.check(lib.ndmps_syevd_topk_recover_f64(1, sizes, k_max, ews.data_ptr(), ebytes, C.byref(recovered), stream))
-            if world > 1:
-                flag = torch.tensor([recovered.value], dtype=torch.int32, device=device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-                if int(flag.item()) and not recovered.value:
+            def solve():
+                _lib.check(lib.ndmps_syevd_topk_values_f64(1, gm.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(),
+                                                           n, k_cap, ews.data_ptr(), ebytes, stream))
+                _lib.check(lib.ndmps_syevd_topk_vectors_auto_f64(1, sizes, k_cap, cut, ranks_dev[t:].data_ptr(), None, 0,
+                                                                 status_dev[t:].data_ptr(), ews.data_ptr(), ebytes, stream))
+
+            solve()
+            if 128 < n <= 512:  # the resident tridiagonalisation may have run: did it give up anywhere?
+                gave_up = int(status_dev[t].item()) == 2
+                if _all_max(gave_up, device, world, group):
+                    _lib.check(lib.ndmps_syevd_topk_note_team_fallback())
                     was = lib.ndmps_syevd_topk_set_team(0)
                     try:
-                        values()
+                        solve()
                     finally:
                         lib.ndmps_syevd_topk_set_team(was)
-            sigma = np.sqrt(np.maximum(w.cpu().numpy()[:k_max], 0.0))
-            k = _kept(sigma, cutoff, chi)
-            if world > 1:
-                # every rank holds the same eigenvalues as long as the all-reduce is replicated bit for bit; the rank
-                # is what fixes the shapes of everything that follows, so it is agreed on explicitly
-                kt = torch.tensor([k], dtype=torch.int64, device=device)
-                dist.broadcast(kt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                k = int(kt.item())
-            status = (C.c_int * 1)()
-            _lib.check(lib.ndmps_syevd_topk_vectors_f64(1, sizes, _lib.i64_array([k]), k_max, ews.data_ptr(), ebytes, status,
-                                                        stream))
-            if status[0] != 0:
-                raise _lib.NdmpsHipError(f"site {i}: the eigen-solver reported status {status[0]}")
-            basis = v[:, :k].to(torch.float32).contiguous()            # (n, k): the k leading eigenvectors
-            cores[i] = basis.t().contiguous().view(k, dims[i], chi_r)  # rows of V^T, like the single-GPU sweep
-            nxt = torch.empty(rows_local * k, dtype=torch.float32, device=device)
-            _lib.check(lib.ndmps_sgemm(0, 0, rows_local, k, n, a.data_ptr(), n, basis.data_ptr(), k, nxt.data_ptr(), k, stream))
-            carried, chi_r = nxt, k
-            i -= 1
+            basis = v[: n * n].view(n, n)[:, :k_cap].to(torch.float32).contiguous()  # (n, k_cap), zero beyond the rank
+            cores[i] = basis.t().contiguous().view(k_cap, dims[i], chi_r)             # rows of V^T, like the single-GPU sweep
+            nxt = pong[t & 1][: rows_local * k_cap]
+            _lib.check(lib.ndmps_sgemm(0, 0, rows_local, k_cap, n, a.data_ptr(), n, basis.data_ptr(), k_cap, nxt.data_ptr(),
+                                       k_cap, stream))
+            carried = nxt
+        # ---- ranks and status of every sharded site in one copy; cores and the carried matrix cut to the ranks
+        chi_r = 1
+        if sites:
+            ranks = [int(r) for r in ranks_dev.cpu().numpy()[: len(sites)]]
+            bad = [(sites[t][0], int(st)) for t, st in enumerate(status_dev.cpu().numpy()[: len(sites)]) if st != 0]
+            if bad:
+                raise _lib.NdmpsHipError(f"the eigen-solver reported (site, status) {bad}")
+            right = 1
+            for t, (i, n, rows_local, _c, k_cap) in enumerate(sites):
+                cores[i] = cores[i][: ranks[t], :, :right].contiguous()
+                right = ranks[t]
+            last = sites[-1]
+            carried = carried.view(last[2], last[4])[:, : ranks[-1]].contiguous().view(-1)
+            chi_r = ranks[-1]
+        i = i_head
         # ---- the rest on every rank: gather the carried matrix (rows of sites 0..i, chi_r columns)
         # what is left runs replicated: the gathered carried matrix plus the ordinary sweep's workspace must fit
         head = dims[:i] + [dims[i] * chi_r]     # the carried matrix as a tensor whose last "site" is (d_i, chi_{i+1})
@@ -131,12 +156,13 @@ def from_dense_sharded(local_dense, dims, max_bond, cutoff: float = 1e-10, group
                                        (C.c_int64 * (len(head) + 1))(), (C.c_int64 * (len(head) + 1))(), C.byref(wsb)))
         need = 2 * carried.numel() * world * 4 + int(wsb.value)
         free, _total = torch.cuda.mem_get_info(device)
-        if need > free:
+        if _all_max(need > free, device, world, group):  # a rank that cannot hold it stops every rank, before the gather
             raise MemoryError(
                 f"the replicated part of the sharded sweep (sites 0..{i}: {carried.numel() * world} carried elements "
                 f"gathered on every rank + {int(wsb.value)} bytes of sweep workspace = {need} bytes) does not fit the "
-                f"{free} bytes free on {device}; use more ranks only if the left sites stay sharded (the loop stops "
-                f"sharding once a rank holds fewer than max(n_i, 256) rows)")
+                f"free memory of every rank ({free} bytes free on this rank's {device}); use more ranks only if the "
+                f"left sites stay sharded (the loop stops sharding once a rank holds fewer than max(n_i, 256) rows)")
+
         def gathered():
             if world > 1:
                 parts = [torch.empty_like(carried) for _ in range(world)]
@@ -155,13 +181,19 @@ def from_dense_sharded(local_dense, dims, max_bond, cutoff: float = 1e-10, group
         ws = torch.empty(int(wsb.value), dtype=torch.uint8, device=device)
         bonds = (C.c_int64 * (Lh + 1))()
         spectra = (C.c_double * max(int(spec_off[Lh]), 1))()
+
         def sweep():
             _lib.check(lib.ndmps_tt_sweep_f32(full.data_ptr(), Lh, cdims, float(cutoff), chi, arena.data_ptr(), core_off,
                                               bonds, spectra, spec_off, ws.data_ptr(), int(wsb.value), stream))
 
+        gave_up = 0
         try:
             sweep()
-        except _lib.NdmpsTeamAbort:  # the sweep overwrote its input: gather again, column launches this time
+        except _lib.NdmpsTeamAbort:
+            gave_up = 1
+        # the sweep overwrote its input, and the two routes differ in the last bits: if ANY rank's resident launch gave
+        # up, EVERY rank gathers again and repeats the sweep on the column launches
+        if _all_max(gave_up, device, world, group):
             _lib.check(lib.ndmps_syevd_topk_note_team_fallback())
             full = gathered()
             was = lib.ndmps_syevd_topk_set_team(0)

@@ -75,6 +75,9 @@ constexpr int kSpanTridiagColumns = 1;
 constexpr int kSpanTridiagTeam = 2;
 constexpr int kSpanGram = 3;       // Gram launches that take the device-side turn (a lockstep group's raw Gram); `bytes` = flops
 constexpr int kSpanGramSmall = 4;  // every other batched Gram launch; `bytes` = flops
+constexpr int kSpanTridiagPanel = 5;   // panel-blocked tridiagonalisation (orders from 1536 on): two launches per column
+constexpr int kSpanTridiagTail = 6;    // last 128 columns in LDS + eigenvalues by multi-section (single-workgroup kernels)
+constexpr int kSpanEigenVectors = 7;   // inverse iteration, orthonormalisation, back-transformation of the kept vectors
 void* span_begin(hipStream_t s);
 void span_end(void* begin, hipStream_t s, int slot, int64_t launches, int64_t bytes);
 

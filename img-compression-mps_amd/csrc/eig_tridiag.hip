@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -369,7 +370,9 @@ trd_column_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int j) {
 //   * a launch holds at most `team_slots()` workgroups (occupancy x compute units, at most two per CU): every team
 //     of a launch is resident whatever order the dispatcher places workgroups in; larger batches go in several
 //     launches;
-//   * at most one team launch is in flight per device: the turn is taken ON THE DEVICE (ndmps::Turn, util.hip: a
+//   * team launches in flight per device never hold more workgroups together than the device keeps resident: the turn
+//     counts units (a launch that fits half the slots takes one of two, every other launch both) and is taken ON THE
+//     DEVICE (ndmps::Turn, util.hip: a
 //     one-thread kernel in front spins on a lock word, one behind gives it back), because two team kernels from
 //     different streams could each hold slots the other's partial teams wait for.  Ordinary kernels sharing the
 //     GPU end by themselves;
@@ -2149,6 +2152,10 @@ __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
 }
 
 // ------------------------------------------------------------------------------------------ host side
+constexpr bool kTeamXcdDefault = true;   // teams placed XCD by XCD (team_place) when NDMPS_TRD_XCD is not set
+constexpr bool kSymDefault = false;  // half-storage team kernel (batches beyond half the workgroup slots) when NDMPS_TRD_SYM is not set
+constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction when NDMPS_TRD_BAND is not set (0: off)
+
 struct TrdLayout {
   int64_t n_max, lda, kp;
   int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
@@ -2185,14 +2192,17 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_stamps = take(batch * 16 * 8);
   l.t_stride = (n_max + 8) * 4;  // groups of WYB reflectors, WYB^2 doubles each, WYB <= 4
   l.off_tw = take(batch * l.t_stride * 8);
-  // two-stage reduction (orders <= 512, eig_band.inc): exchange vectors, the band, the log of the bulge chase
-  const bool band_ok = n_max <= 512;
+  // two-stage reduction (orders <= 512, eig_band.inc): exchange vectors, the band, the log of the bulge chase -- 2 MB per
+  // order-512 matrix, reserved only when the environment (or the built-in default) selects that route.  The layout is a
+  // function of its arguments and the environment alone: every call of a solve sees the same one.
+  const bool band_ok = n_max <= 512 && (getenv("NDMPS_TRD_BAND") ? atoi(getenv("NDMPS_TRD_BAND")) != 0 : kBandDefault != 0);
+  const bool sym_ok = n_max <= 512 && (getenv("NDMPS_TRD_SYM") ? atoi(getenv("NDMPS_TRD_SYM")) != 0 : kSymDefault);
   l.off_yb = take(band_ok ? batch * 2 * kBandMax * l.lda * 8 : 0);
   l.off_xb = take(band_ok ? batch * 2 * kBandMax * l.lda * 8 : 0);
   l.off_band = take(band_ok ? batch * n_max * 2 * kBandMax * 8 : 0);
   l.q_stride = band_ok ? n_max * (n_max + 2 * kBandMax) : 0;
   l.off_qlog = take(batch * l.q_stride * 8);
-  l.off_yrow = take(band_ok ? batch * 2 * 8 * l.lda * 8 : 0);
+  l.off_yrow = take(sym_ok ? batch * 2 * 8 * l.lda * 8 : 0);
   // panel-blocked reduction (orders above 512, eig_panel.inc)
   const bool panel_ok = n_max > 512;
   l.pnl_blocks = ndmps::ceil_div(n_max, kPnlTB);
@@ -2259,9 +2269,6 @@ thread_local int g_team_off = 0;
 std::atomic<long long> g_team_fallbacks{0};
 std::atomic<int> g_inject_abort{0};
 
-constexpr bool kTeamXcdDefault = true;   // teams placed XCD by XCD (team_place) when NDMPS_TRD_XCD is not set
-constexpr bool kSymDefault = false;  // half-storage team kernel (batches beyond half the workgroup slots) when NDMPS_TRD_SYM is not set
-constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction when NDMPS_TRD_BAND is not set (0: off)
 
 // kernels that need more than 64 KB of dynamic LDS are opted in once per device
 int trd_opt_in() {
@@ -2295,6 +2302,22 @@ int trd_opt_in() {
 
 // Semi-bandwidth of the two-stage reduction for a batch whose largest order is n_max, 0 = one-stage paths.  A pure
 // function of its arguments and the environment: phase 1 and phase 2 of a solve must agree on it.
+// The route phase 1 took on a workspace (semi-bandwidth of the two-stage reduction, 0: one-stage): phase 2 replays
+// the reflector logs of THAT route, whatever the thread's switches say by then (a recovery redoes phase 1 with the
+// resident launches off, i.e. one-stage; phase 2 then must not apply the bulge chase's reflectors).
+std::mutex g_route_mu;
+std::map<const void*, int> g_route;
+void route_store(const void* ws, int bw) {
+  std::lock_guard<std::mutex> lock(g_route_mu);
+  if (g_route.size() > 256) g_route.clear();  // workspaces come and go; a forgotten entry falls back to band_width_for
+  g_route[ws] = bw;
+}
+int route_load(const void* ws, int fallback) {
+  std::lock_guard<std::mutex> lock(g_route_mu);
+  auto it = g_route.find(ws);
+  return it == g_route.end() ? fallback : it->second;
+}
+
 int band_width_for(int64_t n_max) {
   if (n_max > 512 || n_max <= kTail || getenv("NDMPS_TRD_NO_TEAM") || g_team_off) return 0;
   const char* e = getenv("NDMPS_TRD_BAND");
@@ -2480,6 +2503,7 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
   // 512, 2.5 ms for 32, against 2.4 / 3.8 / 5.7 ms of column launches); NDMPS_TRD_NO_TEAM=1 keeps the column
   // launches (A/B timing, tests of that path)
   const int bw = band_width_for(n_max);
+  route_store(w_in.A, bw);
   const bool team = !bw && n_max <= 512 && n_max > kTail && !getenv("NDMPS_TRD_NO_TEAM") && !g_team_off;
   if (bw) {
     // two-stage reduction (eig_band.inc): dense -> band with one exchange per panel, then the bulge chase
@@ -2566,7 +2590,7 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
         else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
         else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
       }
-    }, narrow_team || (int64_t)std::min(per_launch, batch) * team_size <= slots / 2));
+    }, (int64_t)std::min(per_launch, batch) * team_size <= slots / 2));  // half a turn only for what fits half the slots
     // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
     for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
     ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, span_bytes);
@@ -2599,7 +2623,7 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
     NDMPS_TRY(pnl_run(seq, batch, h_n, n_max, desc, w, s));
     // nothing is pending when the tail kernel takes over: its update of "the last column launch" must vanish
     NDMPS_CHECK_HIP(hipMemsetAsync(w.y, 0, (size_t)batch * 2 * l.lda * 8, s));
-    ndmps::span_end(span, s, ndmps::kSpanTridiagColumns, 2 * (int64_t)std::max(J_max, 0), span_bytes);
+    ndmps::span_end(span, s, ndmps::kSpanTridiagPanel, (int64_t)seq.size(), span_bytes);
   } else {
     for (int j = 0; j < n_max - kTail; ++j) {
       hipLaunchKernelGGL(column, dim3(W, B), dim3(256), col_lds, s, desc, w, j);
@@ -2613,11 +2637,13 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
   // in LDS -- 70 registers per thread, it starts beside the resident kernel's last workgroups (158 would wait)
   const char* tail_env = getenv("NDMPS_TRD_TAIL");
   const bool tail_regs = tail_env ? !strcmp(tail_env, "regs") : batch < 16;
+  void* tail_span = ndmps::span_begin(s);
   if (tail_regs) hipLaunchKernelGGL(trd_tail_reg_kernel, dim3(1, B), dim3(512), 0, s, desc, w);
   else hipLaunchKernelGGL(trd_tail_kernel, dim3(1, B), dim3(512), kTailLds, s, desc, w);
   const int kk = (int)std::min(k_max, n_max);
   hipLaunchKernelGGL(trd_bisect_kernel, dim3(ndmps::ceil_div(kk, 4), B), dim3(256),
                      (size_t)ndmps::round_up(n_max, 16) * 16, s, desc, w, kk);
+  ndmps::span_end(tail_span, s, ndmps::kSpanTridiagTail, 2, 0);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }
@@ -2682,6 +2708,7 @@ namespace {
 int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* desc, const TrdWork& w, hipStream_t s) {
   const unsigned B = (unsigned)batch;
   const int k16 = (kk + 15) & ~15;
+  void* vec_span = ndmps::span_begin(s);
   hipLaunchKernelGGL(trd_invit_kernel, dim3(1, B), dim3(512),
                      std::max((size_t)n_max * 16, (size_t)2 * 4 * (w.kp <= 64 ? 32 : 16) * w.kp * 8), s, desc, w);
   if (k16 <= 64)
@@ -2690,7 +2717,7 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
     hipLaunchKernelGGL(trd_ortho_blocks_kernel, dim3(1, B), dim3(512), (size_t)3 * 64 * 65 * 8, s, desc, w);
   else
     hipLaunchKernelGGL(trd_ortho_kernel<false>, dim3(1, B), dim3(512), (size_t)k16 * (k16 + 1) * 8, s, desc, w);
-  const int bw = band_width_for(n_max);
+  const int bw = route_load(w.A, band_width_for(n_max));
   if (bw) {  // eigenvectors of T -> eigenvectors of the band matrix: the bulge chase's reflectors, sweeps in reverse
     const dim3 grid((unsigned)ndmps::ceil_div(std::min<int64_t>(k16, w.kp), 32), B);
     if (bw == 2) hipLaunchKernelGGL(trd_back2_kernel<2>, grid, dim3(1024), (size_t)n_max * 32 * 8, s, desc, w, kk);
@@ -2713,6 +2740,7 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
   else if (per64 <= 32) NDMPS_BACK(64, 32, 2, 2);
   else NDMPS_BACK(64, 64, 1, 1);
 #undef NDMPS_BACK
+  ndmps::span_end(vec_span, s, ndmps::kSpanEigenVectors, 4, 0);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }

@@ -147,6 +147,17 @@ ssim_finish_kernel(const double* __restrict__ partial, int64_t n_slices, int til
   if (threadIdx.x == 0) out[0] = red[0] / (double)n_slices;
 }
 
+// one value per slice: sum of its tile partials / map size (the per-slice list of ssim_3d_axis)
+__global__ void __launch_bounds__(256)
+ssim_slices_kernel(const double* __restrict__ partial, int64_t n_slices, int tiles, double map_size,
+                   double* __restrict__ out) {
+  const int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (z >= n_slices) return;
+  double s = 0.0;
+  for (int t = 0; t < tiles; ++t) s += partial[z * tiles + t];  // fixed order, as ssim_finish_kernel
+  out[z] = s / map_size;
+}
+
 __global__ void __launch_bounds__(256)
 psnr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, double* __restrict__ partial) {
   __shared__ double rs[4];
@@ -268,6 +279,50 @@ extern "C" int ndmps_ssim_f32(const float* d_a, const float* d_b, int ndim, cons
     total += axis_mean;
   }
   *h_out = total / p.n_axes;
+  return NDMPS_OK;
+}
+
+// ssim_3d_axis(a, b, axis) (metrics.py:35-65): the SSIM of every 2-D slice along `axis` of a 3-D volume, b clipped at
+// 0, each slice with its own joint data range and the window of its own extent.  h_out: shape[axis] values.  Same
+// kernels as ndmps_ssim_f32 (whose 3-D value is the mean over the three axes of the means of these lists); workspace
+// as ndmps_ssim_workspace_bytes(3, shape) + 8 * shape[axis].
+extern "C" int64_t ndmps_ssim_slices_workspace_bytes(const int64_t* h_shape, int axis) {
+  if (!h_shape || axis < 0 || axis > 2) return -1;
+  const int64_t base = ndmps_ssim_workspace_bytes(3, h_shape);
+  return base < 0 ? -1 : base + 8 * h_shape[axis] + 256;
+}
+extern "C" int ndmps_ssim_slices_f32(const float* d_a, const float* d_b, const int64_t* h_shape, int axis, double* h_out,
+                                     void* d_ws, int64_t ws_bytes, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_a && d_b && h_shape && h_out, "NULL SSIM argument");
+  NDMPS_REQUIRE(axis >= 0 && axis <= 2, "Invalid axis %d for 3D SSIM.", axis);
+  SsimPlan p;
+  NDMPS_TRY(ssim_plan(3, h_shape, p));
+  const int64_t need = ndmps_ssim_slices_workspace_bytes(h_shape, axis);
+  NDMPS_REQUIRE(need >= 0, "win_size exceeds image extent (every slice needs at least 3 x 3 pixels)");
+  if (!d_ws || ws_bytes < need) {
+    ndmps::set_error("SSIM workspace too small: %lld < %lld", (long long)ws_bytes, (long long)need);
+    return NDMPS_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const Slicing& sl = p.sl[axis];
+  const int w = win_for(sl.H, sl.W);
+  const int64_t nz = p.n_slices[axis];
+  const int64_t oh = sl.H - w + 1, ow = sl.W - w + 1;
+  const unsigned gx = (unsigned)ndmps::ceil_div(ow, TW), gy = (unsigned)ndmps::ceil_div(oh, TH);
+  NDMPS_REQUIRE(nz < 2147483647LL && gy < 65536, "SSIM grid too large");
+  double* range = (double*)d_ws;
+  double* partial = range + nz;
+  double* values = partial + nz * gx * gy;
+  hipLaunchKernelGGL(slice_range_kernel, dim3((unsigned)nz), dim3(256), 0, s, d_a, d_b, sl, range);
+  for (int64_t z0 = 0; z0 < nz; z0 += 65535) {
+    const unsigned gz = (unsigned)std::min<int64_t>(65535, nz - z0);
+    hipLaunchKernelGGL(ssim_tile_kernel, dim3(gx, gy, gz), dim3(256), 0, s, d_a, d_b, sl, w, range, partial, z0);
+  }
+  hipLaunchKernelGGL(ssim_slices_kernel, dim3((unsigned)ndmps::ceil_div(nz, 256)), dim3(256), 0, s, partial, nz,
+                     (int)(gx * gy), (double)(oh * ow), values);
+  NDMPS_LAUNCH_CHECK();
+  NDMPS_CHECK_HIP(hipMemcpyAsync(h_out, values, sizeof(double) * nz, hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   return NDMPS_OK;
 }
 

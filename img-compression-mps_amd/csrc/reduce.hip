@@ -9,6 +9,10 @@
 #include <algorithm>
 #include <vector>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -433,8 +437,21 @@ int dct_fft_launch_n(const float* src, float* dst, int64_t rows, int64_t n, hipS
   const size_t lds = (size_t)(M + 2 * (M + 1)) * sizeof(Cf) + (size_t)4 * (n + 4 * M) * sizeof(float);
   // exactly the workgroups the device keeps resident at once (every workgroup loops over rows: a partly filled second
   // round of workgroups would leave a third of the GPU idle for half the kernel)
-  int per_cu = 0;
-  NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dct_fft_kernel<INVERSE, NN>, 256, lds));
+  // asked once per (direction, instantiation, row length, device): the query costs host time on every volume otherwise
+  static std::mutex mu;
+  static std::map<std::pair<int, int64_t>, int> cache;
+  int dev = 0, per_cu = 0;
+  NDMPS_CHECK_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({dev, n});
+    if (it == cache.end()) {
+      NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dct_fft_kernel<INVERSE, NN>, 256, lds));
+      cache[{dev, n}] = per_cu;
+    } else {
+      per_cu = it->second;
+    }
+  }
   const int grid = (int)std::min<int64_t>((rows + 3) / 4, (int64_t)ndmps::kNumCU * std::max(per_cu, 1));
   hipLaunchKernelGGL((dct_fft_kernel<INVERSE, NN>), dim3(grid), dim3(256), lds, s, src, dst, rows, (int)n);
   NDMPS_LAUNCH_CHECK();

@@ -451,6 +451,11 @@ int ndmps_dequantize_f32(const void* d_q, int64_t n, float lo, float hi, int bit
 int64_t ndmps_ssim_workspace_bytes(int ndim, const int64_t* h_shape);
 int ndmps_ssim_f32(const float* d_a, const float* d_b, int ndim, const int64_t* h_shape,
                    double* h_out, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
+/* ssim_3d_axis(a, b, axis) (utils/metrics.py:35-65): the SSIM of every 2-D slice along `axis` (0, 1, 2) of a 3-D
+ * volume, h_out[shape[axis]]; the 3-D value of ndmps_ssim_f32 is the mean over the axes of the means of these lists. */
+int64_t ndmps_ssim_slices_workspace_bytes(const int64_t* h_shape, int axis);
+int ndmps_ssim_slices_f32(const float* d_a, const float* d_b, const int64_t* h_shape, int axis, double* h_out,
+                          void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
 int64_t ndmps_psnr_workspace_bytes(void);
 int ndmps_psnr_f32(const float* d_a, const float* d_b, int64_t n, double* h_out, void* d_ws,
                    int64_t ws_bytes, ndmps_stream_t stream);

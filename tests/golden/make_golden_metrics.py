@@ -13,7 +13,7 @@ import numpy as np
 
 sys.path.insert(0, "/root/reference/src")
 import skimage  # noqa: E402
-from imgcompressionmps.utils.metrics import compute_psnr, compute_ssim_by_dim  # noqa: E402
+from imgcompressionmps.utils.metrics import compute_psnr, compute_ssim_by_dim, ssim_3d_axis  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -28,6 +28,9 @@ def main():
         out[name + "/b"] = b
         out[name + "/ssim"] = np.float64(compute_ssim_by_dim(a, b))
         out[name + "/psnr"] = np.float64(compute_psnr(a, b))
+        if len(shape) == 3:  # the per-slice lists of ssim_3d_axis (metrics.py:35-65), one per axis
+            for axis in range(3):
+                out[f"{name}/ssim_axis{axis}"] = np.asarray(ssim_3d_axis(a, b, axis), dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
     print("wrote metrics.npz with skimage", skimage.__version__)
 

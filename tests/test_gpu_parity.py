@@ -1445,6 +1445,38 @@ def test_device_ssim_psnr_match_oracle_and_reference_fixtures(golden_dir):
         dm.compute_ssim_by_dim(np.zeros((2, 9), dtype=np.float32), np.zeros((2, 9), dtype=np.float32))
 
 
+def test_device_ssim_3d_axis_lists_match_the_reference_fixture(golden_dir):
+    """ssim_3d_axis (utils/metrics.py:35-65): the per-slice lists along each axis against the lists the reference's own
+    function produced (tests/golden/make_golden_metrics.py, skimage 0.18.3) and against the oracle on the same fp32
+    values; a volume with negative values (the clip), the axis checks, negative axis numbers."""
+    from imgcompressionmps_amd.utils import metrics as dm
+    from oracle import metrics as om
+
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    a32, b32 = g["3d/a"].astype(np.float32), g["3d/b"].astype(np.float32)
+    means = []
+    for axis in range(3):
+        got = dm.ssim_3d_axis(a32, b32, axis)
+        assert isinstance(got, list) and len(got) == a32.shape[axis]
+        want = om.ssim_3d_axis(a32.astype(np.float64), b32.astype(np.float64), axis)
+        assert np.abs(np.array(got) - np.array(want)).max() <= 1e-12
+        assert np.abs(np.array(got) - g[f"3d/ssim_axis{axis}"]).max() <= 5e-6  # the reference ran on the fp64 arrays
+        means.append(np.mean(got))
+    assert abs(np.mean(means) - dm.compute_ssim_by_dim(a32, b32)) <= 1e-12
+    assert dm.ssim_3d_axis(a32, b32, -1) == dm.ssim_3d_axis(a32, b32, 2)
+    x = synthetic_mri((48, 40, 56), seed=9)
+    y = x + 0.03 * np.random.default_rng(1).standard_normal(x.shape).astype(np.float32)  # negative values: clip
+    for axis in range(3):
+        want = om.ssim_3d_axis(x.astype(np.float64), y.astype(np.float64), axis)
+        assert np.abs(np.array(dm.ssim_3d_axis(torch.from_numpy(x).to(DEV), y, axis)) - np.array(want)).max() <= 1e-12
+    with pytest.raises(ValueError):
+        dm.ssim_3d_axis(x, y, 3)
+    with pytest.raises(ValueError):
+        dm.ssim_3d_axis(x, y[:-1], 0)
+    with pytest.raises(ValueError):
+        dm.ssim_3d_axis(x[0], y[0], 0)
+
+
 def test_device_ssim_256_cubed_against_oracle_sample():
     """Full-size SSIM on the device; the oracle checks one axis' worth of slices (host SSIM of a
     whole 256^3 pair takes ~10 s) plus the full value on a 96^3 crop."""

@@ -238,3 +238,90 @@ def test_half_storage_reduction_gives_lapacks_eigenpairs(lib, monkeypatch):
             vk = vv[b, : n * n].reshape(n, n)[:, :kb]
             assert np.abs(vk.T @ vk - np.eye(kb)).max() < 1e-12, n
             assert np.abs(m @ vk - vk * wv[b, :kb]).max() < 1e-12 * ref[0], n
+
+
+def test_two_streams_of_narrow_teams_share_the_gpu_without_giving_up(lib):
+    """Eight order-512 matrices run with 8-column blocks: 512 workgroups, every resident slot of the GPU.  Two such
+    launches from two streams must not be in flight together (each would hold slots the other's teams wait for, both
+    would spin out their 3 s and fall back): a launch takes half a turn only if it fits half the slots.  Both streams
+    finish, nobody gives up, and the eigenvalues are LAPACK's."""
+    import threading
+
+    n, k, batch = 512, 64, 8
+    before = int(lib.ndmps_syevd_topk_team_fallbacks())
+    mats = [np.stack([_spd(n, 100 * t + b) for b in range(batch)]) for t in range(2)]
+    out, errs = [None, None], []
+
+    def run(t):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                dg = torch.from_numpy(mats[t]).to(DEV)
+                v = torch.empty_like(dg)
+                w = torch.empty((batch, n), dtype=torch.float64, device=DEV)
+                nbytes = int(lib.ndmps_syevd_topk_workspace_bytes(n, batch, k))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+                sizes = _lib.i64_array([n] * batch)
+                for _ in range(3):
+                    _lib.check(lib.ndmps_syevd_topk_values_f64(batch, dg.data_ptr(), n * n, sizes, v.data_ptr(), n * n,
+                                                               w.data_ptr(), n, k, ws.data_ptr(), nbytes, _lib.stream_ptr()))
+                torch.cuda.current_stream().synchronize()
+                out[t] = w.cpu().numpy()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    took = time.perf_counter() - t0
+    assert not errs, errs
+    assert int(lib.ndmps_syevd_topk_team_fallbacks()) == before
+    assert took < 2.5, f"two streams of eight order-512 matrices took {took:.2f} s: a team waited for its time-out"
+    for t in range(2):
+        for b in range(batch):
+            ref = np.linalg.eigvalsh(mats[t][b])[::-1]
+            assert np.abs(out[t][b, :k] - ref[:k]).max() <= 2e-13 * ref[0]
+
+
+def test_the_solver_switch_is_per_host_thread(lib):
+    """ndmps_syevd_topk_set_team(0) -- what a retry after an aborted resident launch sets around its second attempt --
+    acts on the calling host thread only (a thread_local in the library): while one thread holds the switch off, a
+    lockstep group encoded on another thread still takes the resident launches and gets, bit for bit, what it gets
+    with nobody else around; the thread that holds the switch gets the column launches' result, bit for bit."""
+    import threading
+
+    xs = [synthetic_mri((64, 64, 64), seed=2025 + j) for j in range(2)]
+    chi = 32  # eigenproblems of order 256 at the middle sites: the resident launch is on their path
+
+    def encode():
+        return [o.to_tensor() for o in NDMPS.from_tensors(xs, max_bond=chi, device=DEV, dtype=torch.float64)]
+
+    clean = encode()
+    assert lib.ndmps_syevd_topk_set_team(0) == 1
+    columns = encode()
+    assert lib.ndmps_syevd_topk_set_team(1) == 0
+    assert any(not np.array_equal(a, b) for a, b in zip(clean, columns)), "the two routes agree bit for bit: no test"
+    off, done = threading.Event(), threading.Event()
+    seen = {}
+
+    def holder():
+        seen["was"] = lib.ndmps_syevd_topk_set_team(0)
+        off.set()
+        done.wait(timeout=120)
+        seen["columns"] = encode()
+        seen["back"] = lib.ndmps_syevd_topk_set_team(1)
+
+    th = threading.Thread(target=holder)
+    th.start()
+    assert off.wait(timeout=60)
+    beside = encode()  # this thread's switch is untouched
+    assert lib.ndmps_syevd_topk_set_team(1) == 1
+    done.set()
+    th.join(timeout=180)
+    assert seen["was"] == 1 and seen["back"] == 0
+    for a, b in zip(clean, beside):
+        assert np.array_equal(a, b)
+    for a, b in zip(columns, seen["columns"]):
+        assert np.array_equal(a, b)

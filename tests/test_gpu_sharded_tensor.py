@@ -128,6 +128,99 @@ def test_sharded_sweep_two_ranks_all_reduce_the_gram_matrices(shape, chi):
     assert sorted(results) == [(0, True), (1, True)], results
 
 
+def _worker_with_aborts(rank, world, port, shape, chi, inject_on, count, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = _lib.load()
+        before = int(lib.ndmps_syevd_topk_team_fallbacks())
+        if rank == inject_on:
+            lib.ndmps_debug_inject_team_abort(count)
+        ok = bool(_check_against_single_gpu(synthetic_mri(shape, seed=5), chi, rank, world))
+        lib.ndmps_debug_inject_team_abort(0)
+        q.put((rank, ok, int(lib.ndmps_syevd_topk_team_fallbacks()) - before))
+    except Exception as exc:  # the assertion text travels back to the parent
+        q.put((rank, f"{type(exc).__name__}: {exc}", -1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sweep_a_resident_launch_that_gives_up_on_one_rank_sends_every_rank_to_the_column_launches():
+    """128^3 at chi = 32: the sharded sites 4 and 3 (order 256) and the replicated rest take the resident
+    tridiagonalisation (the replicated rest, an 8 x 8 x 256 tensor, has none).  On rank 1 the next two resident launches
+    are replaced by what an aborted one leaves behind (status 2).  Every decision is collective -- rank 0, whose
+    launches were fine, redoes the same sites on the column launches -- so nobody hangs in an unmatched collective,
+    both ranks count the same two fall-backs, and the result is the single-GPU sweep's and the oracle's."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_with_aborts, args=(r, 2, port, (128, 128, 128), 32, 1, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True, 2), (1, True, 2)], results
+
+
+def _worker_tail_abort(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = _lib.load()
+        # site dims chosen so that the REPLICATED rest holds a resident launch: site 3 (order 32) is sharded, site 2
+        # (order 8 * 32 = 256, 400 rows in all, 200 per rank) is not, and its 400 x 256 unfolding is tall
+        dims, chi = [2, 200, 8, 32], 32
+        rng = np.random.default_rng(7)
+        dense = np.einsum("ia,ajb,bkc,cl->ijkl", rng.standard_normal((2, 6)), rng.standard_normal((6, 200, 9)),
+                          rng.standard_normal((9, 8, 40)), rng.standard_normal((40, 32)))
+        dense = (dense + 1e-3 * rng.standard_normal(dense.shape)).astype(np.float32)
+        flat = torch.from_numpy(dense.reshape(-1)).to(DEV)
+        n_local = flat.numel() // world
+        before = int(lib.ndmps_syevd_topk_team_fallbacks())
+        if rank == 1:
+            lib.ndmps_debug_inject_team_abort(1)
+        mps = sharded.from_dense_sharded(flat[rank * n_local:(rank + 1) * n_local].clone(), dims, max_bond=chi)
+        lib.ndmps_debug_inject_team_abort(0)
+        counted = int(lib.ndmps_syevd_topk_team_fallbacks()) - before
+        cores, _ = omps.mps_from_dense(dense.astype(np.float64), dims, max_bond=chi)
+        want = omps.mps_to_dense(cores).reshape(-1)
+        got = mps.to_dense().double().cpu().numpy().reshape(-1)
+        ok = mps.bond_sizes() == [int(c.shape[2]) for c in cores[:-1]] and \
+            float(np.linalg.norm(got - want)) <= 2e-5 * float(np.linalg.norm(want))
+        q.put((rank, bool(ok), counted))
+    except Exception as exc:  # the assertion text travels back to the parent
+        q.put((rank, f"{type(exc).__name__}: {exc}", -1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sweep_an_abort_in_the_replicated_rest_is_repeated_by_every_rank():
+    """The replicated rest of the sweep overwrites its gathered input; when its resident launch gives up on ONE rank,
+    EVERY rank gathers again (a collective) and repeats it on the column launches -- decided by an all-reduce every
+    rank joins, not in an except branch only the aborting rank would take."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_tail_abort, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True, 1), (1, True, 1)], results
+
+
 @pytest.mark.parametrize("shape", [(64, 64, 64), (48, 40, 36), (32, 32, 16, 24), (512, 680), (128, 128, 128)])
 def test_top_level_blocks_are_the_rows_of_the_site_order_tensor(shape):
     """Bit-exact: encoding a rank's top-level blocks on their own gives its rows of the full site-order tensor."""

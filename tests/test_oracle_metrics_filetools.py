@@ -18,6 +18,9 @@ def test_ssim_psnr_against_reference(golden_dir):
     with pytest.raises(ValueError):
         om.compute_ssim_by_dim(np.zeros(4), np.zeros(4))
     assert om.compute_psnr(a, a) == np.inf
+    for axis in range(3):  # the per-slice lists of the reference's ssim_3d_axis (metrics.py:35-65)
+        got = om.ssim_3d_axis(g["3d/a"], g["3d/b"], axis)
+        assert np.abs(np.array(got) - g[f"3d/ssim_axis{axis}"]).max() <= 1e-12
 
 
 def test_filetools_against_reference(golden_dir):
