@@ -99,6 +99,7 @@ SIGNATURES = {
     "ndmps_syevj_batched_vectors_f64": (C.c_int, [C.c_int, vp, i64, p_i64, vp, i64, vp, i64, p_i64, vp, i64, vp]),
     "ndmps_syevd_topk_max_n": (i64, []),
     "ndmps_syevd_topk_max_k": (i64, []),
+    "ndmps_syevd_topk_max_k_wide": (i64, []),
     "ndmps_syevd_topk_workspace_bytes": (i64, [i64, C.c_int, i64]),
     "ndmps_syevd_topk_stamps_offset": (i64, [i64, C.c_int, i64]),
     "ndmps_syevd_topk_values_f64": (C.c_int, [C.c_int, vp, i64, p_i64, vp, i64, vp, i64, i64, vp, i64, vp]),

@@ -77,6 +77,7 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   double* d;           // [B][n_max] diagonal of T
   double* e;           // [B][n_max] sub-diagonal of T
   double* lam;         // [B][n_max] eigenvalues of T / bound, descending
+  double* mu;          // [B][n_max] shifts of the inverse iteration: lam with coinciding values spread apart (trd_shift_kernel)
   double* bound;       // [B] Gershgorin bound of T
   double* Z;           // [B][n_max][kp] eigenvectors of T
   double* lu;          // [B][4][n_max][kp] dl, 1/d, du, du2 of the pivoted factorisations
@@ -1241,6 +1242,27 @@ __global__ void __launch_bounds__(256) trd_bisect_kernel(const TrdDesc* __restri
   }
 }
 
+// Shifts of the inverse iteration: the eigenvalues of T / bound, descending, with values closer than 10 eps spread
+// 10 eps apart (LAPACK dstein's rule).  Several columns iterated with the SAME shift converge to the same vector when
+// T has structure below the resolution of its eigenvalues -- the Gram matrix of an isometric core is the identity plus
+// rounding noise, its 512 eigenvalues are a handful of distinct doubles, and 512 columns collapsed onto a few (the
+// Cholesky-QR of the block then breaks down).  Shifts a few ulp outside such a cluster return the random starts
+// themselves, which is what an invariant subspace without preferred directions should get.  One thread per matrix.
+__global__ void trd_shift_kernel(const TrdDesc* __restrict__ desc, TrdWork w, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const int k = min(desc[b].k, desc[b].n);
+  const double* lam = w.lam + (int64_t)b * w.n_max;
+  double* mu = w.mu + (int64_t)b * w.n_max;
+  constexpr double kPertol = 10.0 * 2.220446049250313e-16;  // T is scaled to |T| <= 1
+  double prev = 0.0;
+  for (int c = 0; c < k; ++c) {
+    const double m = c == 0 ? lam[0] : fmin(lam[c], prev - kPertol);
+    mu[c] = m;
+    prev = m;
+  }
+}
+
 // ------------------------------------------------------------------------- inverse iteration + CholQR
 __device__ __forceinline__ double hash_uniform(unsigned a, unsigned b) {
   unsigned x = a * 0x9E3779B1u + b * 0x85EBCA77u + 0x165667B1u;
@@ -1398,6 +1420,11 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   TrdDesc& d = desc[blockIdx.y];
   const int n = d.n, k = d.k, kp = w.kp;
   const int tid = threadIdx.x;
+  // column block of this workgroup: all kp <= 128 columns, or columns [128 x, 128 x + 128) of a wider block (k > 128:
+  // every eigenpair wanted, exact sweeps); kb: width of the block's tiles in LDS, kl: wanted columns inside it
+  const int cbase = (int)blockIdx.x * kMaxK;
+  const int kb = min(kp - cbase, kMaxK), kl = max(min(k - cbase, kMaxK), 0);
+  if (kb <= 0) return;
   const int64_t b = blockIdx.y;
   const double* dd = w.d + b * w.n_max;
   const double* ee = w.e + b * w.n_max;
@@ -1418,12 +1445,13 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   // factorisation reads it, and that is over before the first S is stored
   double2* te = reinterpret_cast<double2*>(lds);
   long long* stamp = w.stamps + b * 16;
-  if (tid == 0) stamp[0] = wall_clock64();
+  const bool stamping = blockIdx.x == 0;
+  if (tid == 0 && stamping) stamp[0] = wall_clock64();
   for (int i = tid; i < n; i += 512) te[i] = make_double2(dd[i] * inv, i + 1 < n ? ee[i] * inv : 0.0);
   __syncthreads();
-  if (tid < k) {
-    const int c = tid;
-    const double mu = w.lam[b * w.n_max + c];
+  if (tid < kl) {
+    const int c = cbase + tid;
+    const double mu = w.mu[b * w.n_max + c];
     // ---- factorisation (scaled T: |T| <= 1) fused with the first forward sweep on the random start
     double di = te[0].x - mu;             // current diagonal
     double ui = te[0].y;                  // current super-diagonal du[i]
@@ -1466,7 +1494,7 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
     if (di == 0.0) di = kEps;
     DI[(int64_t)(n - 1) * kp + c] = fast_rcp<2>(di);
     Z[(int64_t)(n - 1) * kp + c] = xi;  // last component of the fused forward sweep
-    if (tid == 0) stamp[1] = wall_clock64();
+    if (tid == 0 && stamping) stamp[1] = wall_clock64();
   }
   __syncthreads();  // the factors and the first forward sweep are visible to the whole workgroup
 
@@ -1478,16 +1506,16 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   // values per row and lane, the division of the back substitution folded into them), and carry the results of
   // the block before from an LDS out-buffer back to Z with coalesced stores.
   {
-    const int SB = kp <= 64 ? 32 : 16;
-    const int per_arr = SB * kp;               // doubles per operand array and block (2048)
+    const int SB = kb <= 64 ? 32 : 16;
+    const int per_arr = SB * kb;               // doubles per operand array and block (2048)
     constexpr int HN = 384, EPT = 6;           // helper threads, elements per helper and array (EPT HN >= per_arr)
     double* ring = lds;                         // [2][3][per_arr]
     double* outb = lds + 6 * per_arr;           // [2][per_arr]
     double st0[3][EPT], st1[3][EPT];            // two register stages x 3 arrays
-    const bool solver = tid < k;
+    const bool solver = tid < kl;
     const bool helper = tid >= 128;
     const int ht = tid - 128;
-    const int c = tid;
+    const int c = cbase + tid;
     double xi = solver ? Z[(int64_t)(n - 1) * kp + c] : 0.0;  // last component of the fused first forward sweep
     for (int sweep = 0; sweep < 3; ++sweep) {
       const bool backward = sweep != 1;
@@ -1499,10 +1527,10 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
           const int e = ht + HN * u;
-          const int s2 = e / kp, cc = e % kp;
+          const int s2 = e / kb, cc = e % kb;
           const int r = row_of(blk, s2);
           const bool ok = e < per_arr && blk < nblk && r >= 0 && r <= n - 2;
-          const int64_t o = (int64_t)(ok ? r : 0) * kp + cc;
+          const int64_t o = (int64_t)(ok ? r : 0) * kp + cbase + cc;
           if (backward) {  // x_r = (z_r - du_r x_{r+1} - du2_r x_{r+2}) / d_r, the division folded in
             const double di = ok ? DI[o] : 0.0;
             dst[0][u] = ok ? Z[o] * di : 0.0;
@@ -1531,9 +1559,9 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
           const int e = ht + HN * u;
-          const int s2 = e / kp, cc = e % kp;
+          const int s2 = e / kb, cc = e % kb;
           const int r = row_of(blk, s2);
-          if (e < per_arr && cc < k && r >= 0 && r <= n - 2) Z[(int64_t)r * kp + cc] = ob[e];
+          if (e < per_arr && cc < kl && r >= 0 && r <= n - 2) Z[(int64_t)r * kp + cbase + cc] = ob[e];
         }
       };
       double x1 = 0.0, x2 = 0.0;
@@ -1560,13 +1588,13 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
           fetch(blk + 2, refill);
           if (blk >= 1) write_back(blk - 1);
         } else if (solver) {
-          const double* buf = ring + (blk & 1) * 3 * per_arr + c;
-          double* ob = outb + (blk & 1) * per_arr + c;
+          const double* buf = ring + (blk & 1) * 3 * per_arr + tid;
+          double* ob = outb + (blk & 1) * per_arr + tid;
           for (int s0 = 0; s0 < SB; s0 += CH) {  // eight rows' operands out of LDS, then eight steps of the chain
             double o0[CH], o1[CH], o2[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-              const int e = (s0 + u) * kp;
+              const int e = (s0 + u) * kb;
               o0[u] = buf[e];
               o1[u] = buf[per_arr + e];
               o2[u] = buf[2 * per_arr + e];
@@ -1577,7 +1605,7 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
               const bool in = r >= 0 && r <= n - 2;
               if (backward) {
                 const double x0 = fma(-o1[u], x1, fma(-o2[u], x2, o0[u]));
-                ob[(s0 + u) * kp] = x0;
+                ob[(s0 + u) * kb] = x0;
                 if (in) {
                   x2 = x1;
                   x1 = x0;
@@ -1585,7 +1613,7 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
               } else {
                 const bool sw = o2[u] != 0.0;
                 const double top = sw ? o0[u] : xi, bot = sw ? xi : o0[u];
-                ob[(s0 + u) * kp] = top;
+                ob[(s0 + u) * kb] = top;
                 if (in) xi = fma(-o1[u], top, bot);
               }
             }
@@ -1602,9 +1630,9 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
     }
   }
   // pad columns of the block stay zero
-  if (k < kp)
-    for (int e = tid; e < n * (kp - k); e += 512) Z[(int64_t)(e / (kp - k)) * kp + k + e % (kp - k)] = 0.0;
-  if (tid == 0) stamp[2] = wall_clock64();
+  if (kl < kb)
+    for (int e = tid; e < n * (kb - kl); e += 512) Z[(int64_t)(e / (kb - kl)) * kp + cbase + kl + e % (kb - kl)] = 0.0;
+  if (tid == 0 && stamping) stamp[2] = wall_clock64();
 }
 
 // Orthonormalisation of the n x k block Z (its own kernel: the recurrences above and the products below have
@@ -2144,6 +2172,7 @@ __global__ void trd_clear_status_kernel(TrdDesc* __restrict__ desc, int batch, T
 #include "eig_band.inc"
 #include "eig_sym.inc"
 #include "eig_panel.inc"
+#include "eig_wide.inc"
 
 // Test hook (ndmps_debug_inject_team_abort): what an aborted team launch leaves behind, without the 3 s wait
 __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
@@ -2158,8 +2187,9 @@ constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction wh
 
 struct TrdLayout {
   int64_t n_max, lda, kp;
-  int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
+  int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_mu, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
   int64_t off_pv, off_pw, off_ypart, off_spart, off_ucol, off_napart, pnl_blocks, pnl_tiles;
+  int64_t off_ws, off_wlinv, off_wgram, kw, wgram_bytes;  // more than kMaxK vectors (eig_wide.inc)
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -2184,6 +2214,7 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_d = take(batch * n_max * 8);
   l.off_e = take(batch * n_max * 8);
   l.off_lam = take(batch * n_max * 8);
+  l.off_mu = take(batch * n_max * 8);
   l.off_bound = take(batch * 8);
   l.off_z = take(batch * n_max * l.kp * 8);
   l.off_lu = take(batch * 4 * n_max * l.kp * 8);
@@ -2213,6 +2244,13 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_spart = take(panel_ok ? batch * l.pnl_tiles * 8 : 0);
   l.off_ucol = take(panel_ok ? batch * 2 * l.lda * 8 : 0);
   l.off_napart = take(panel_ok ? batch * 2 * l.pnl_blocks * kPnlNa * 8 : 0);
+  // more than kMaxK eigenvectors (eig_wide.inc): Gram matrix, L^-1 and the Gram kernel's partial tiles, one set for
+  // the whole batch (its matrices are orthonormalised one after the other)
+  l.kw = k_max > kMaxK ? ndmps::round_up(k_max, kWB) : 0;
+  l.wgram_bytes = l.kw ? ndmps_gram_f64_workspace_bytes(n_max, k_max) : 0;
+  l.off_ws = take(l.kw * l.kw * 8);
+  l.off_wlinv = take(l.kw * l.kw * 8);
+  l.off_wgram = take(l.wgram_bytes);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -2231,6 +2269,7 @@ TrdWork trd_work(const TrdLayout& l, void* d_ws) {
   w.d = (double*)(base + l.off_d);
   w.e = (double*)(base + l.off_e);
   w.lam = (double*)(base + l.off_lam);
+  w.mu = (double*)(base + l.off_mu);
   w.bound = (double*)(base + l.off_bound);
   w.Z = (double*)(base + l.off_z);
   w.lu = (double*)(base + l.off_lu);
@@ -2290,6 +2329,8 @@ int trd_opt_in() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_ortho_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kInvitLdsMax));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_chol_diag_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kWB * kWLd * (int)sizeof(double)));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_ortho_blocks_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 65 * 8));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_back2_kernel<2>),
@@ -2652,14 +2693,19 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
 
 // phase marks of the inverse-iteration kernel of matrix b (16 x int64, 100 MHz): profiling aid
 extern "C" int64_t ndmps_syevd_topk_stamps_offset(int64_t n_max, int batch, int64_t k_max) {
-  if (n_max <= 0 || n_max > kMaxN || batch <= 0 || k_max <= 0 || k_max > kMaxK) return -1;
+  if (n_max <= 0 || n_max > kMaxN || batch <= 0 || k_max <= 0 || k_max > kMaxN) return -1;
   return trd_layout(n_max, batch, std::min(k_max, n_max)).off_stamps;
 }
 extern "C" int64_t ndmps_syevd_topk_max_n(void) { return kMaxN; }
 extern "C" int64_t ndmps_syevd_topk_max_k(void) { return kMaxK; }
 
+// largest k of the two-phase calls (ndmps_syevd_topk_values_f64 / _vectors_f64): every eigenpair of any order the solver
+// takes.  Above ndmps_syevd_topk_max_k() vectors the orthonormalisation runs across the chip (eig_wide.inc); the
+// device-side rank decision (ndmps_syevd_topk_vectors_auto_f64) stays with at most ndmps_syevd_topk_max_k().
+extern "C" int64_t ndmps_syevd_topk_max_k_wide(void) { return kMaxN; }
+
 extern "C" int64_t ndmps_syevd_topk_workspace_bytes(int64_t n_max, int batch, int64_t k_max) {
-  if (n_max <= 0 || n_max > kMaxN || batch <= 0 || k_max <= 0 || k_max > kMaxK) return 0;
+  if (n_max <= 0 || n_max > kMaxN || batch <= 0 || k_max <= 0 || k_max > kMaxN) return 0;
   return trd_layout(n_max, batch, std::min(k_max, n_max)).total;
 }
 
@@ -2671,7 +2717,7 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
   int64_t n_max = 0;
   NDMPS_TRY(trd_check_sizes(batch, h_n, n_max));
   NDMPS_REQUIRE(d_G && d_V && d_w, "NULL eigen operand");
-  NDMPS_REQUIRE(k_max >= 1 && k_max <= kMaxK, "k_max=%lld outside [1, %d]", (long long)k_max, kMaxK);
+  NDMPS_REQUIRE(k_max >= 1 && k_max <= kMaxN, "k_max=%lld outside [1, %d]", (long long)k_max, kMaxN);
   for (int b = 0; b < batch; ++b)
     NDMPS_REQUIRE(stride_G >= h_n[b] * h_n[b] && stride_V >= h_n[b] * h_n[b] && stride_w >= h_n[b],
                   "batch stride smaller than a matrix");
@@ -2705,13 +2751,26 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
 namespace {
 // inverse iteration + back-transformation for ranks already stored in the descriptors; kk: largest rank any
 // matrix may have (sizes the launches), k_fill: columns zero-filled beyond a matrix's rank
-int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* desc, const TrdWork& w, hipStream_t s) {
+int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* desc, const TrdWork& w, hipStream_t s,
+                       const TrdLayout* wide_layout = nullptr, void* d_ws = nullptr, const int64_t* h_n = nullptr,
+                       const int64_t* h_k = nullptr) {
   const unsigned B = (unsigned)batch;
   const int k16 = (kk + 15) & ~15;
   void* vec_span = ndmps::span_begin(s);
-  hipLaunchKernelGGL(trd_invit_kernel, dim3(1, B), dim3(512),
-                     std::max((size_t)n_max * 16, (size_t)2 * 4 * (w.kp <= 64 ? 32 : 16) * w.kp * 8), s, desc, w);
-  if (k16 <= 64)
+  hipLaunchKernelGGL(trd_shift_kernel, dim3((unsigned)ndmps::ceil_div(batch, 64)), dim3(64), 0, s, desc, w, batch);
+  // inverse iteration in column blocks of kMaxK (one block up to 128 wanted vectors)
+  const int kb = std::min<int>(w.kp, kMaxK);
+  hipLaunchKernelGGL(trd_invit_kernel, dim3((unsigned)ndmps::ceil_div(w.kp, kMaxK), B), dim3(512),
+                     std::max((size_t)n_max * 16, (size_t)2 * 4 * (kb <= 64 ? 32 : 16) * kb * 8), s, desc, w);
+  if (w.kp > kMaxK) {
+    // more than 128 vectors may be wanted: Cholesky-QR across the chip, matrix by matrix (eig_wide.inc)
+    NDMPS_REQUIRE(wide_layout && d_ws && h_n && h_k && wide_layout->kw > 0, "wide eigenvector block without its workspace");
+    char* base = (char*)d_ws;
+    for (int b = 0; b < batch; ++b)
+      NDMPS_TRY(wide_orthonormalise(desc + b, w.Z + (int64_t)b * w.n_max * w.kp, (int)h_n[b], (int)h_k[b], w.kp,
+                                    (double*)(base + wide_layout->off_ws), (double*)(base + wide_layout->off_wlinv),
+                                    (int)wide_layout->kw, base + wide_layout->off_wgram, wide_layout->wgram_bytes, s));
+  } else if (k16 <= 64)
     hipLaunchKernelGGL(trd_ortho_kernel<true>, dim3(1, B), dim3(512), (size_t)2 * k16 * (k16 + 1) * 8, s, desc, w);
   else if (!getenv("NDMPS_ORTHO_COLUMNS"))  // k > 64: column blocks of 64 (block Gram-Schmidt + blocked Cholesky-QR)
     hipLaunchKernelGGL(trd_ortho_blocks_kernel, dim3(1, B), dim3(512), (size_t)3 * 64 * 65 * 8, s, desc, w);
@@ -2786,7 +2845,7 @@ extern "C" int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const
   int64_t n_max = 0;
   NDMPS_TRY(trd_check_sizes(batch, h_n, n_max));
   NDMPS_REQUIRE(h_k, "NULL rank array");
-  NDMPS_REQUIRE(k_max >= 1 && k_max <= kMaxK, "k_max=%lld outside [1, %d]", (long long)k_max, kMaxK);
+  NDMPS_REQUIRE(k_max >= 1 && k_max <= kMaxN, "k_max=%lld outside [1, %d]", (long long)k_max, kMaxN);
   const TrdLayout l = trd_layout(n_max, batch, std::min(k_max, n_max));
   if (d_ws == nullptr || ws_bytes < l.total) {
     ndmps::set_error("syevd_topk workspace too small: %lld < %lld", (long long)ws_bytes, (long long)l.total);
@@ -2807,7 +2866,7 @@ extern "C" int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const
     for (int t = 0; t < count; ++t) chunk.v[t] = (int)h_k[base + t];
     hipLaunchKernelGGL(trd_setk_kernel, dim3(1), dim3(256), 0, s, desc, chunk, base, count);
   }
-  NDMPS_TRY(trd_launch_vectors(batch, n_max, kk, 0, desc, w, s));
+  NDMPS_TRY(trd_launch_vectors(batch, n_max, kk, 0, desc, w, s, &l, d_ws, h_n, h_k));
   if (h_status) {
     std::vector<TrdDesc> host(batch);
     NDMPS_CHECK_HIP(hipMemcpyAsync(host.data(), desc, sizeof(TrdDesc) * batch, hipMemcpyDeviceToHost, s));
@@ -2830,7 +2889,7 @@ extern "C" int ndmps_syevd_topk_recover_f64(int batch, const int64_t* h_n, int64
                                             int* h_recovered, ndmps_stream_t stream) {
   int64_t n_max = 0;
   NDMPS_TRY(trd_check_sizes(batch, h_n, n_max));
-  NDMPS_REQUIRE(k_max >= 1 && k_max <= kMaxK, "k_max=%lld outside [1, %d]", (long long)k_max, kMaxK);
+  NDMPS_REQUIRE(k_max >= 1 && k_max <= kMaxN, "k_max=%lld outside [1, %d]", (long long)k_max, kMaxN);
   const TrdLayout l = trd_layout(n_max, batch, std::min(k_max, n_max));
   if (d_ws == nullptr || ws_bytes < l.total) {
     ndmps::set_error("syevd_topk workspace too small: %lld < %lld", (long long)ws_bytes, (long long)l.total);

@@ -314,11 +314,34 @@ inline bool use_topk(int64_t n_max, int64_t max_bond) {
   if (getenv("NDMPS_SWEEP_JACOBI")) return false;  // A/B timing
   return max_bond > 0 && max_bond <= ndmps_syevd_topk_max_k() && n_max <= ndmps_syevd_topk_max_n();
 }
+// Sweeps that want every eigenpair above a cutoff (no bond cap, or one beyond the direct solver's 128) take the direct
+// solver too, with the eigenvectors orthonormalised across the chip (eig_wide.inc), while its workspace -- four
+// n x n planes of LU factors per matrix -- stays below kDirectFullBytes; orders beyond its limit stay on the block Jacobi.
+constexpr int64_t kDirectFullBytes = (int64_t)48 << 30;
+inline bool use_direct_full(int64_t n_max, int batch, int64_t max_bond) {
+  if (getenv("NDMPS_SWEEP_JACOBI") || getenv("NDMPS_EXACT_JACOBI")) return false;  // A/B timing
+  if (max_bond > 0 && max_bond <= ndmps_syevd_topk_max_k()) return false;            // the bond-capped path
+  if (n_max > ndmps_syevd_topk_max_n()) return false;
+  const int64_t need = ndmps_syevd_topk_workspace_bytes(n_max, batch, n_max);
+  return need > 0 && need <= kDirectFullBytes;
+}
 inline int64_t eig_workspace_bytes(int64_t n_max, int batch, int64_t max_bond) {
   const int64_t jac = ndmps_syevj_batched_workspace_bytes(n_max, batch);
   if (max_bond > 0 && max_bond <= ndmps_syevd_topk_max_k() && n_max <= ndmps_syevd_topk_max_n())
     return std::max(jac, ndmps_syevd_topk_workspace_bytes(n_max, batch, std::min(max_bond, n_max)));
+  if (use_direct_full(n_max, batch, max_bond)) return std::max(jac, ndmps_syevd_topk_workspace_bytes(n_max, batch, n_max));
   return jac;
+}
+// The direct solver leaves eigenvalue errors of up to ~1e-14 |G| (measured 6e-16 at order 4096, tools/full_probe.py).
+// A rank decided against a cutoff c (relative, on the singular values) cannot be moved by them unless an eigenvalue
+// sits within 1e-13 |G| of the threshold c^2 w_0 -- under the tiny cutoffs of exact sweeps that is every (numerically)
+// zero eigenvalue of a rank-deficient matrix.  Then the block Jacobi decides, as before.
+inline bool direct_rank_is_safe(const double* w_desc, int64_t n, double c) {
+  if (n < 1) return true;
+  const double thr = c * c * w_desc[0], delta = 1e-13 * fabs(w_desc[0]);
+  for (int64_t i = 0; i < n; ++i)
+    if (fabs(w_desc[i] - thr) <= delta) return false;
+  return true;
 }
 
 // upper bound of ndmps_gram_workspace_bytes(m, n') over every n' <= n (the actual bond may
@@ -680,17 +703,32 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       for (int b = 0; b < batch; ++b) kept[b] = k_cap;
       return NDMPS_OK;
     }
+    bool full = !topk && use_direct_full(lay.small_max, batch, max_bond);  // every eigenpair above the cutoff, direct solver
     if (topk) {
       NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, k_cap, ev_ws,
                                             ev_ws_bytes, s));
       // the host waits for the eigenvalues anyway: a resident launch that gave up is redone on the column launches
       NDMPS_TRY(ndmps_syevd_topk_recover_f64(batch, eig_n.data(), k_cap, ev_ws, ev_ws_bytes, nullptr, s));
-    } else
+    } else if (full) {
+      NDMPS_TRY(ndmps_syevd_topk_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, lay.small_max, ev_ws,
+                                            ev_ws_bytes, s));
+      NDMPS_TRY(ndmps_syevd_topk_recover_f64(batch, eig_n.data(), lay.small_max, ev_ws, ev_ws_bytes, nullptr, s));
+    }
+    if (topk || full) {
+      NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max, hipMemcpyDeviceToHost, s));
+      NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+      if (full) {  // a rank the solver's own noise could move is decided by the Jacobi (G is untouched)
+        const double c = std::max(cutoff, cutoff_floor<T>());
+        for (int b = 0; b < batch; ++b)
+          if (!direct_rank_is_safe(host_w.data() + (int64_t)b * lay.small_max, eig_n[b], c)) full = false;
+      }
+    }
+    if (!topk && !full) {
       NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, sweep_eig_tol(sizeof(T) == 8),
                                                ev_ws, ev_ws_bytes, &sweeps, s));
-    NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max,
-                                   hipMemcpyDeviceToHost, s));
-    NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+      NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max, hipMemcpyDeviceToHost, s));
+      NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+    }
     for (int b = 0; b < batch; ++b) {
       const int64_t small = eig_n[b];
       std::vector<double> sv(host_w.begin() + (int64_t)b * lay.small_max,
@@ -704,12 +742,22 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
                std::min(small, room) * sizeof(double));
       }
     }
-    if (topk) {
+    if (topk || full) {
       eig_status.assign(batch, 0);
-      NDMPS_TRY(ndmps_syevd_topk_vectors_f64(batch, eig_n.data(), kept.data(), k_cap, ev_ws, ev_ws_bytes,
+      NDMPS_TRY(ndmps_syevd_topk_vectors_f64(batch, eig_n.data(), kept.data(), topk ? k_cap : lay.small_max, ev_ws, ev_ws_bytes,
                                              eig_status.data(), s));
+      bool redo = false;
       for (int b = 0; b < batch; ++b)
-        if (eig_status[b] != 0) return solver_failed(i, b, eig_status[b]);
+        if (eig_status[b] != 0) {
+          if (!full) return solver_failed(i, b, eig_status[b]);
+          redo = true;  // the wide block lost rank (a cluster tighter than the shifts resolve): the Jacobi has no such case
+        }
+      if (redo) {
+        NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max,
+                                                 sweep_eig_tol(sizeof(T) == 8), ev_ws, ev_ws_bytes, &sweeps, s));
+        NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(), ev_ws,
+                                                  ev_ws_bytes, s));
+      }
     } else {
       NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(),
                                                 ev_ws, ev_ws_bytes, s));
@@ -1158,6 +1206,14 @@ struct BondLayout {
 };
 }  // namespace
 
+namespace {
+// eigen workspace of compress_bond: the block Jacobi's, and the direct solver's for every eigenpair where it applies
+inline int64_t bond_eig_bytes(int64_t chi) {
+  const int64_t jac = ndmps_syevj_workspace_bytes(chi);
+  return use_direct_full(chi, 1, 0) ? std::max(jac, ndmps_syevd_topk_workspace_bytes(chi, 1, chi)) : jac;
+}
+}  // namespace
+
 extern "C" int64_t ndmps_compress_bond_workspace_bytes(int64_t chi_l, int64_t d1, int64_t chi, int64_t d2,
                                                        int64_t chi_r) {
   if (chi_l <= 0 || d1 <= 0 || chi <= 0 || d2 <= 0 || chi_r <= 0) return 0;
@@ -1177,7 +1233,7 @@ extern "C" int64_t ndmps_compress_bond_workspace_bytes(int64_t chi_l, int64_t d1
   used = arena_bytes(used, 8, c2);       // A1 in the storage type
   used = arena_bytes(used, 8, c2);       // B2 in the storage type
   used = arena_bytes(used, 8, chi * n2); // t2 in fp64
-  used = arena_bytes(used, 1, ndmps_syevj_workspace_bytes(chi));
+  used = arena_bytes(used, 1, bond_eig_bytes(chi));
   used = arena_bytes(used, 1, std::max(ndmps_gram_workspace_bytes(m1, chi), ndmps_gram_f64_workspace_bytes(m1, chi)));
   return ndmps::round_up(used, 256) + 256;
 }
@@ -1216,7 +1272,7 @@ int compress_bond_impl(const T* d_t1, const T* d_t2, int64_t chi_l, int64_t d1, 
   T* A1 = reinterpret_cast<T*>(ar.take<double>(c2));
   T* B2 = reinterpret_cast<T*>(ar.take<double>(c2));
   double* t2d = ar.take<double>(chi * n2);
-  const int64_t ev_bytes = ndmps_syevj_workspace_bytes(chi);
+  const int64_t ev_bytes = bond_eig_bytes(chi);
   char* ev_ws = ar.take<char>(ev_bytes);
   const int64_t gram_bytes = std::max(ndmps_gram_workspace_bytes(m1, chi), ndmps_gram_f64_workspace_bytes(m1, chi));
   char* gram_ws = ar.take<char>(gram_bytes);
@@ -1229,18 +1285,52 @@ int compress_bond_impl(const T* d_t1, const T* d_t2, int64_t chi_l, int64_t d1, 
   hipLaunchKernelGGL(f32_to_f64_kernel<T>, dim3(grid1d(chi * n2)), dim3(256), 0, s, d_t2, chi * n2, t2d);
   NDMPS_LAUNCH_CHECK();
   NDMPS_TRY(ndmps_dgemm(0, 1, chi, chi, n2, t2d, n2, t2d, n2, G2, chi, s));
-  NDMPS_TRY(ndmps_syevj_f64(G2, chi, Lt, w2, ev_ws, ev_bytes, &sweeps, s));
+  // Both decompositions on the direct solver where it applies (every eigenpair of G2 for its square root; of H the
+  // eigenvalues, then only the kept vectors), the block Jacobi otherwise -- and for H whenever the solver's own noise
+  // could move the rank (direct_rank_is_safe).
+  const bool direct = use_direct_full(chi, 1, 0);
+  const int64_t n1[1] = {chi};
+  auto direct_values = [&](const double* M, double* vecs, double* vals) -> int {
+    NDMPS_TRY(ndmps_syevd_topk_values_f64(1, M, c2, n1, vecs, c2, vals, chi, chi, ev_ws, ev_bytes, s));
+    return ndmps_syevd_topk_recover_f64(1, n1, chi, ev_ws, ev_bytes, nullptr, s);
+  };
+  auto direct_vectors = [&](int64_t kv, bool& ok) -> int {  // ok = false: the block lost rank, the caller takes the Jacobi
+    const int64_t k1[1] = {kv};
+    int status = 0;
+    NDMPS_TRY(ndmps_syevd_topk_vectors_f64(1, n1, k1, chi, ev_ws, ev_bytes, &status, s));
+    if (status == 2) return solver_failed(-1, 0, status);
+    ok = status == 0;
+    return NDMPS_OK;
+  };
+  bool g2_direct = direct;
+  if (g2_direct) {
+    NDMPS_TRY(direct_values(G2, Lt, w2));
+    NDMPS_TRY(direct_vectors(chi, g2_direct));
+  }
+  if (!g2_direct) NDMPS_TRY(ndmps_syevj_f64(G2, chi, Lt, w2, ev_ws, ev_bytes, &sweeps, s));
   hipLaunchKernelGGL(scale_cols_sqrt_kernel, dim3(grid1d(c2)), dim3(256), 0, s, Lt, chi, chi, w2);
   NDMPS_LAUNCH_CHECK();
   NDMPS_TRY(ndmps_dgemm(0, 0, chi, chi, chi, G1, chi, Lt, chi, tmp, chi, s));
   NDMPS_TRY(ndmps_dgemm(1, 0, chi, chi, chi, Lt, chi, tmp, chi, H, chi, s));
-  NDMPS_TRY(ndmps_syevj_f64(H, chi, V, wh, ev_ws, ev_bytes, &sweeps, s));  // symmetrises H on entry
-
   std::vector<double> sv(chi);
-  NDMPS_CHECK_HIP(hipMemcpyAsync(sv.data(), wh, chi * sizeof(double), hipMemcpyDeviceToHost, s));
-  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  bool h_direct = direct;
+  if (h_direct) {
+    NDMPS_TRY(direct_values(H, V, wh));  // the solver symmetrises its copy of H
+    NDMPS_CHECK_HIP(hipMemcpyAsync(sv.data(), wh, chi * sizeof(double), hipMemcpyDeviceToHost, s));
+    NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+    h_direct = direct_rank_is_safe(sv.data(), chi, std::max(cutoff, cutoff_floor<T>()));
+  }
+  if (!h_direct) {
+    NDMPS_TRY(ndmps_syevj_f64(H, chi, V, wh, ev_ws, ev_bytes, &sweeps, s));  // symmetrises H on entry
+    NDMPS_CHECK_HIP(hipMemcpyAsync(sv.data(), wh, chi * sizeof(double), hipMemcpyDeviceToHost, s));
+    NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  }
   for (auto& x : sv) x = sqrt(std::max(x, 0.0));  // eigenvalues of H are s^2
   const int64_t k = kept_rank(sv, cutoff, max_bond, cutoff_floor<T>());
+  if (h_direct) {
+    NDMPS_TRY(direct_vectors(k, h_direct));
+    if (!h_direct) NDMPS_TRY(ndmps_syevj_f64(H, chi, V, wh, ev_ws, ev_bytes, &sweeps, s));  // same spectrum, same k
+  }
   if (h_s) memcpy(h_s, sv.data(), chi * sizeof(double));
   *h_new_chi = k;
 

@@ -239,9 +239,15 @@ int ndmps_syevj_batched_vectors_f64(int batch, double* d_G, int64_t stride_G, co
  * quimb's from_dense calls per site, core/ndmps.py:74).  Same conventions as ndmps_syevj_*: w descending,
  * eigenvector c in column c of V (ld n), largest-magnitude component positive.  Two phases like the Jacobi
  * pair above; both are asynchronous on `stream` (vectors synchronises only when h_status is given;
- * h_status[b] != 0: the orthonormalisation of matrix b broke down). */
+ * h_status[b] != 0: the orthonormalisation of matrix b broke down).
+ * The two-phase calls take any k_max <= ndmps_syevd_topk_max_k_wide() (= every eigenpair of the largest order): the
+ * exact sweeps and compress() want all eigenpairs above a cutoff (core/ndmps.py:74,104-106: dgesdd through quimb).
+ * Above ndmps_syevd_topk_max_k() wanted vectors the eigenvectors of T are iterated in column blocks of 128 and
+ * orthonormalised across the chip (Gram matrix on the fp64 MFMA, blocked Cholesky, one-launch triangular solve:
+ * csrc/eig_wide.inc).  Orders from 1536 on are tridiagonalised panel by panel (csrc/eig_panel.inc). */
 int64_t ndmps_syevd_topk_max_n(void);
 int64_t ndmps_syevd_topk_max_k(void);
+int64_t ndmps_syevd_topk_max_k_wide(void);
 int64_t ndmps_syevd_topk_workspace_bytes(int64_t n_max, int batch, int64_t k_max);
 /* byte offset, inside the workspace, of 16 int64 wall-clock marks (100 MHz) per matrix left by the vectors
  * phase (profiling aid, tools/trd_probe.py) */

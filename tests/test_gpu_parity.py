@@ -841,6 +841,42 @@ def test_topk_solver_panel_path_against_the_column_launches(monkeypatch):
         assert np.abs(v @ v.T - v3 @ v3.T).max() <= 50 * 2.2e-16 / max(gap, 1e-300) + 1e-11
 
 
+@pytest.mark.parametrize("n,k", [(200, 200), (512, 512), (777, 300), (1024, 1024), (1600, 129)])
+def test_direct_solver_more_than_128_vectors(n, k):
+    """Every eigenpair (or any number beyond 128) of a graded Gram matrix: what exact sweeps and compress() ask for
+    (core/ndmps.py:74,104-106 of the reference: dgesdd).  Inverse iteration in column blocks of 128, Cholesky-QR of the
+    whole n x k block across the chip (csrc/eig_wide.inc), against LAPACK at the tolerances of the narrow solver."""
+    lib = _lib.load()
+    assert int(lib.ndmps_syevd_topk_max_k_wide()) >= 4096
+    rng = np.random.default_rng(n + k)
+    a = rng.standard_normal((n + 5, n)) * np.logspace(0, -4, n)[None, :]
+    q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    g = q @ (a.T @ a) @ q.T
+    g = 0.5 * (g + g.T)
+    (w, v), = _topk(lib, [g], [k], k_max=max(k, min(n, 400)))
+    _check_topk(g, w, v, k, k_max=max(k, min(n, 400)))
+    if k == n:  # a full decomposition: V diag(w) V^T gives the matrix back
+        assert np.abs((v * w[None, :]) @ v.T - g).max() <= 2e-15 * max(n, 50) * np.abs(g).max()
+
+
+def test_direct_solver_all_vectors_of_degenerate_spectra():
+    """All eigenvectors where they are not unique: the identity (an n-fold eigenvalue: every start vector is an
+    eigenvector and the block is a random matrix until it is orthonormalised), the zero matrix, rank one, exact
+    multiplicities, a volume's Gram matrix with its noise floor, mixed orders in one batch."""
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    n = 300
+    u = rng.standard_normal(n)
+    q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    lam = np.r_[np.full(10, 5.0), np.full(120, 1.0), np.linspace(0.5, 0.1, n - 130)]
+    x = synthetic_mri((32, 32, 32), seed=3).astype(np.float64).reshape(-1, 256)
+    cases = [np.eye(n), np.zeros((200, 200)), np.outer(u, u), (q * lam) @ q.T, x.T @ x]
+    mats = [0.5 * (g + g.T) for g in cases]
+    ks = [m.shape[0] for m in mats]
+    for g, k, (w, v) in zip(mats, ks, _topk(lib, mats, ks)):
+        _check_topk(g, w, v, k, tol_scale=4.0)
+
+
 def test_topk_solver_volume_gram_matrices_with_noise_floor_clusters():
     """The matrices the sweep meets: Gram matrices of the chi-capped unfoldings of a noisy volume, a few large
     eigenvalues over a floor of ~n near-equal ones (gaps ~1e-9 of the largest).  The kept subspace must agree
