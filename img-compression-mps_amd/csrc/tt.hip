@@ -53,6 +53,36 @@ inline int grid1d(int64_t n) {
 }
 
 // ----------------------------------------------------------------------------- small kernels
+// |A v_j|^2 for the eigenvectors v_j = V[:, i0 + j], j < t, of a Gram matrix of A: the singular values behind the SMALLEST
+// eigenvalues, which the eigenvalues themselves resolve only to ~1e-15 |G| (3e-8 of the largest singular value).
+// A(r, c) = A[r rs + c cs] (rs = n, cs = 1 for G = A^T A; the transposed strides for G = A A^T).  Thread (row, j):
+// 4 rows x 64 columns per workgroup; partial[blockIdx.x][j] = sum over the workgroup's rows; tail_norm_reduce_kernel
+// adds the row blocks in fixed order.
+template <typename T>
+__global__ void __launch_bounds__(256)
+tail_norm_partial_kernel(const T* __restrict__ A, int64_t rs, int64_t cs, int rows, int cols, const double* __restrict__ V,
+                         int ldv, int i0, int t, double* __restrict__ partial) {
+  __shared__ double red[4][64];
+  const int jl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.y * 64 + jl, r = blockIdx.x * 4 + rl;
+  double y = 0.0;
+  if (r < rows && j < t) {
+    const T* a = A + (int64_t)r * rs;
+    const double* v = V + i0 + j;
+    for (int c = 0; c < cols; ++c) y = fma(ndmps::to_f64(a[(int64_t)c * cs]), v[(int64_t)c * ldv], y);
+  }
+  red[rl][jl] = y * y;
+  __syncthreads();
+  if (rl == 0 && j < t) partial[(int64_t)blockIdx.x * t + j] = (red[0][jl] + red[1][jl]) + (red[2][jl] + red[3][jl]);
+}
+__global__ void tail_norm_reduce_kernel(const double* __restrict__ partial, int nblk, int t, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * t + j];
+  out[j] = s;
+}
+
 template <typename T = float>
 __global__ void __launch_bounds__(256) f32_to_f64_kernel(const T* __restrict__ x, int64_t n, double* y) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -332,13 +362,22 @@ inline int64_t eig_workspace_bytes(int64_t n_max, int batch, int64_t max_bond) {
   if (use_direct_full(n_max, batch, max_bond)) return std::max(jac, ndmps_syevd_topk_workspace_bytes(n_max, batch, n_max));
   return jac;
 }
-// The direct solver leaves eigenvalue errors of up to ~1e-14 |G| (measured 6e-16 at order 4096, tools/full_probe.py).
-// A rank decided against a cutoff c (relative, on the singular values) cannot be moved by them unless an eigenvalue
-// sits within 1e-13 |G| of the threshold c^2 w_0 -- under the tiny cutoffs of exact sweeps that is every (numerically)
-// zero eigenvalue of a rank-deficient matrix.  Then the block Jacobi decides, as before.
-inline bool direct_rank_is_safe(const double* w_desc, int64_t n, double c) {
+// The direct solver leaves eigenvalue errors of up to ~1e-14 |G| (measured 6e-16 at order 4096, tools/full_probe.py):
+// eigenvalues within kDirectDoubt |G| of the threshold c^2 w_0 cannot decide a rank -- under the tiny cutoffs of exact
+// sweeps that is the whole lower end of the spectrum of a square noisy unfolding (its smallest singular values reach
+// zero) and every numerically zero eigenvalue of a rank-deficient matrix.  First index (descending order) from which
+// the eigenvalues are in doubt; n: none.
+constexpr double kDirectDoubt = 1e-13;
+inline int64_t direct_doubt_from(const double* w_desc, int64_t n, double c) {
+  if (n < 1) return n;
+  const double hi = c * c * w_desc[0] + kDirectDoubt * fabs(w_desc[0]);
+  int64_t i = n;
+  while (i > 0 && w_desc[i - 1] <= hi) --i;
+  return i;
+}
+inline bool direct_rank_is_safe(const double* w_desc, int64_t n, double c) {  // nothing in doubt around the threshold
   if (n < 1) return true;
-  const double thr = c * c * w_desc[0], delta = 1e-13 * fabs(w_desc[0]);
+  const double thr = c * c * w_desc[0], delta = kDirectDoubt * fabs(w_desc[0]);
   for (int64_t i = 0; i < n; ++i)
     if (fabs(w_desc[i] - thr) <= delta) return false;
   return true;
@@ -684,10 +723,11 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
   const int64_t spec_total = h_spec_offsets ? h_spec_offsets[L] : 0;
   std::vector<double> host_w((size_t)batch * lay.small_max);
   std::vector<int> eig_status;
+  std::vector<int64_t> doubt;  // first eigenvalue in doubt per matrix (direct solver, every eigenpair wanted)
 
   // One batched eigen-solve for site i on the matrices G[b] (order eig_n[b], ld eig_n[b]): eigenvalues to the
   // host, rank decision per volume (kept[b]), then the kept eigenvectors in the columns of V[b].
-  auto solve_site = [&](int i) -> int {
+  auto solve_site = [&](int i, bool have_a = false) -> int {
     int sweeps = 0;
     int64_t site_n = 0;
     for (int b = 0; b < batch; ++b) site_n = std::max(site_n, eig_n[b]);
@@ -717,10 +757,15 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     if (topk || full) {
       NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max, hipMemcpyDeviceToHost, s));
       NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-      if (full) {  // a rank the solver's own noise could move is decided by the Jacobi (G is untouched)
+      if (full) {
+        // eigenvalues in doubt (direct_doubt_from): with the unfolding at hand their singular values are measured
+        // as |A v| behind the solve (below); without it (merged run) the Jacobi decides (G is untouched)
         const double c = std::max(cutoff, cutoff_floor<T>());
-        for (int b = 0; b < batch; ++b)
-          if (!direct_rank_is_safe(host_w.data() + (int64_t)b * lay.small_max, eig_n[b], c)) full = false;
+        doubt.assign(batch, 0);
+        for (int b = 0; b < batch; ++b) {
+          doubt[b] = direct_doubt_from(host_w.data() + (int64_t)b * lay.small_max, eig_n[b], c);
+          if (doubt[b] < eig_n[b] && !have_a) full = false;
+        }
       }
     }
     if (!topk && !full) {
@@ -735,6 +780,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
                              host_w.begin() + (int64_t)b * lay.small_max + small);
       for (auto& x : sv) x = sqrt(std::max(x, 0.0));
       kept[b] = kept_rank(sv, cutoff, max_bond, cutoff_floor<T>());
+      if (full && doubt[b] < small) kept[b] = small;  // every vector first; the rank follows from |A v| below
       if (h_spectra && h_spec_offsets) {
         // the layout reserves min(m, d_i max_bond_{i+1}) values for the bond; a merged site may be larger
         const int64_t room = h_spec_offsets[i + 1] - h_spec_offsets[i];
@@ -755,8 +801,49 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
       if (redo) {
         NDMPS_TRY(ndmps_syevj_batched_values_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max,
                                                  sweep_eig_tol(sizeof(T) == 8), ev_ws, ev_ws_bytes, &sweeps, s));
+        NDMPS_CHECK_HIP(hipMemcpyAsync(host_w.data(), w, sizeof(double) * batch * lay.small_max, hipMemcpyDeviceToHost, s));
+        NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+        for (int b = 0; b < batch; ++b) {
+          std::vector<double> sv(host_w.begin() + (int64_t)b * lay.small_max, host_w.begin() + (int64_t)b * lay.small_max + eig_n[b]);
+          for (auto& x : sv) x = sqrt(std::max(x, 0.0));
+          kept[b] = kept_rank(sv, cutoff, max_bond, cutoff_floor<T>());
+        }
         NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(), ev_ws,
                                                   ev_ws_bytes, s));
+      } else if (full) {
+        // ---- singular values in doubt, measured: s_j = |A v_j| (or |A^T u_j|) for the eigenvectors from doubt[b] on;
+        //      G (free now) is the scratch.  The kept rank = the vectors in front + those whose s_j passes the cutoff.
+        for (int b = 0; b < batch; ++b) {
+          const int64_t small = eig_n[b], i0 = doubt[b], t = small - i0;
+          if (t <= 0) continue;
+          const int64_t n = h_dims[i] * chi_r[b], m = cur_elems[b] / n;
+          const bool right = n <= m;  // G = A^T A: vectors in R^n, |A v|; else G = A A^T: |A^T u|
+          const int rows = (int)(right ? m : n), cols = (int)(right ? n : m);
+          const int nblk = (int)ceil_div(rows, 4);
+          double* partial = G + (int64_t)b * sq;
+          NDMPS_REQUIRE((int64_t)nblk * t + t <= sq, "internal: no room for the tail norms (%lld x %lld)", (long long)nblk, (long long)t);
+          double* out = partial + (int64_t)nblk * t;
+          hipLaunchKernelGGL(tail_norm_partial_kernel<T>, dim3((unsigned)nblk, (unsigned)ceil_div(t, 64)), dim3(256), 0, s,
+                             (const T*)cur[b], right ? n : (int64_t)1, right ? (int64_t)1 : n, rows, cols,
+                             (const double*)(V + (int64_t)b * sq), (int)small, (int)i0, (int)t, partial);
+          hipLaunchKernelGGL(tail_norm_reduce_kernel, dim3((unsigned)ceil_div(t, 256)), dim3(256), 0, s, partial, nblk, (int)t, out);
+          NDMPS_LAUNCH_CHECK();
+          std::vector<double> s2((size_t)t);
+          NDMPS_CHECK_HIP(hipMemcpyAsync(s2.data(), out, sizeof(double) * t, hipMemcpyDeviceToHost, s));
+          NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+          const double s0 = sqrt(std::max(host_w[(int64_t)b * lay.small_max], 0.0));
+          const double c = std::max(cutoff, cutoff_floor<T>());
+          int64_t k = i0;
+          for (int64_t j = 0; j < t; ++j) k += sqrt(std::max(s2[(size_t)j], 0.0)) > c * s0;
+          k = std::max<int64_t>(k, 1);
+          if (max_bond > 0) k = std::min(k, max_bond);
+          kept[b] = std::min(k, small);
+          if (h_spectra && h_spec_offsets) {
+            const int64_t room = h_spec_offsets[i + 1] - h_spec_offsets[i];
+            for (int64_t j = 0; j < t && i0 + j < room; ++j)
+              h_spectra[(int64_t)b * spec_total + h_spec_offsets[i] + i0 + j] = sqrt(std::max(s2[(size_t)j], 0.0));
+          }
+        }
       }
     } else {
       NDMPS_TRY(ndmps_syevj_batched_vectors_f64(batch, G, sq, eig_n.data(), V, sq, w, lay.small_max, kept.data(),
@@ -1001,7 +1088,7 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
         NDMPS_TRY(ndmps_dgemm(0, 1, m, m, n, Ab, n, Ab, n, Gb, m, s));
       }
     }
-    NDMPS_TRY(solve_site(i));
+    NDMPS_TRY(solve_site(i, true));
     // ---- core and carried matrix: one launch per step for a uniform group, else volume by volume
     bool done = false;
     if (uni && uniform_kept()) {
