@@ -100,6 +100,8 @@ SIGNATURES = {
     "ndmps_syevd_topk_max_n": (i64, []),
     "ndmps_syevd_topk_max_k": (i64, []),
     "ndmps_syevd_topk_max_k_wide": (i64, []),
+    "ndmps_potrf_scratch_elems": (i64, [i64]),
+    "ndmps_potrf_lower_f64": (C.c_int, [vp, i64, vp, C.POINTER(C.c_int), vp]),
     "ndmps_syevd_topk_workspace_bytes": (i64, [i64, C.c_int, i64]),
     "ndmps_syevd_topk_stamps_offset": (i64, [i64, C.c_int, i64]),
     "ndmps_syevd_topk_values_f64": (C.c_int, [C.c_int, vp, i64, p_i64, vp, i64, vp, i64, i64, vp, i64, vp]),

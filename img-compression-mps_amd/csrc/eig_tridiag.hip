@@ -2691,6 +2691,42 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
 
 }  // namespace
 
+// Cholesky factor of a symmetric positive definite matrix: d_S (n x n, ld n, the lower triangle is read) <- L (lower,
+// zeros above), S = L L^T; blocked right-looking on the fp64 MFMA (the kernels of eig_wide.inc).  d_scratch:
+// ndmps_potrf_scratch_elems(n) doubles (the inverses of the diagonal blocks and the breakdown flag).  Synchronises;
+// *h_status = 1 if a pivot was not positive (not numerically positive definite: d_S is then undefined).  compress()
+// takes it for the square root of G2 = T2 T2^T, which any factor with L L^T = G2 serves (tt.hip).
+extern "C" int64_t ndmps_potrf_scratch_elems(int64_t n) {
+  const int64_t kw = ndmps::round_up(std::max<int64_t>(n, 1), kWB);
+  return kw * kw + 64;
+}
+extern "C" int ndmps_potrf_lower_f64(double* d_S, int64_t n, double* d_scratch, int* h_status, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_S && d_scratch && h_status && n >= 1 && n <= 32768, "bad Cholesky argument");
+  NDMPS_TRY(trd_opt_in());
+  hipStream_t s = (hipStream_t)stream;
+  const int k = (int)n, kw = (int)ndmps::round_up(n, kWB), nblk = kw / kWB;
+  double* linv = d_scratch;
+  TrdDesc* d_flag = reinterpret_cast<TrdDesc*>(d_scratch + (int64_t)kw * kw);  // its status word is the breakdown flag
+  NDMPS_CHECK_HIP(hipMemsetAsync(d_flag, 0, sizeof(TrdDesc), s));
+  for (int pb = 0; pb < nblk; ++pb) {
+    const int p = kWB * pb, below = nblk - pb - 1;
+    hipLaunchKernelGGL(wide_chol_diag_kernel, dim3(1), dim3(512), (size_t)2 * kWB * kWLd * sizeof(double), s, d_S, k, linv, kw, k, p,
+                       d_flag);
+    if (below > 0) {
+      hipLaunchKernelGGL(wide_chol_panel_kernel, dim3((unsigned)below), dim3(256), 0, s, d_S, k, (const double*)linv, kw, k, p);
+      hipLaunchKernelGGL(wide_chol_trail_kernel, dim3((unsigned)(below * (below + 1) / 2)), dim3(256), 0, s, d_S, k, k, p);
+    }
+  }
+  hipLaunchKernelGGL(wide_zero_upper_kernel, dim3((unsigned)std::min<int64_t>(ndmps::ceil_div(n * n, 256), 2048)), dim3(256), 0, s,
+                     d_S, k);
+  NDMPS_LAUNCH_CHECK();
+  TrdDesc host;
+  NDMPS_CHECK_HIP(hipMemcpyAsync(&host, d_flag, sizeof(TrdDesc), hipMemcpyDeviceToHost, s));
+  NDMPS_CHECK_HIP(hipStreamSynchronize(s));
+  *h_status = host.status != 0 ? 1 : 0;
+  return NDMPS_OK;
+}
+
 // phase marks of the inverse-iteration kernel of matrix b (16 x int64, 100 MHz): profiling aid
 extern "C" int64_t ndmps_syevd_topk_stamps_offset(int64_t n_max, int batch, int64_t k_max) {
   if (n_max <= 0 || n_max > kMaxN || batch <= 0 || k_max <= 0 || k_max > kMaxN) return -1;

@@ -1389,14 +1389,28 @@ int compress_bond_impl(const T* d_t1, const T* d_t2, int64_t chi_l, int64_t d1, 
     ok = status == 0;
     return NDMPS_OK;
   };
-  bool g2_direct = direct;
-  if (g2_direct) {
-    NDMPS_TRY(direct_values(G2, Lt, w2));
-    NDMPS_TRY(direct_vectors(chi, g2_direct));
+  // Square root of G2: any Lt with Lt Lt^T = G2 serves (H = Lt^T G1 Lt has the singular values squared whatever the
+  // factor, and Lt V_k, G1 Lt V_k do not depend on it).  The Cholesky factor where G2 is numerically positive definite
+  // -- the cores to the right of the bond are isometries until compress() reaches them: G2 = I + rounding, a
+  // chi-fold eigenvalue, the worst case of an eigen-solver and the best of a Cholesky --, else W D^(1/2) from the
+  // eigen-decomposition (zero eigenvalues give zero columns).
+  bool g2_chol = direct && !getenv("NDMPS_COMPRESS_EIG") && ndmps_potrf_scratch_elems(chi) <= 2 * c2;
+  if (g2_chol) {
+    NDMPS_CHECK_HIP(hipMemcpyAsync(Lt, G2, sizeof(double) * c2, hipMemcpyDeviceToDevice, s));
+    int bad = 0;
+    NDMPS_TRY(ndmps_potrf_lower_f64(Lt, chi, tmp, &bad, s));  // tmp and H (adjacent, 2 c2 doubles) are free until Lt is known
+    g2_chol = bad == 0;
   }
-  if (!g2_direct) NDMPS_TRY(ndmps_syevj_f64(G2, chi, Lt, w2, ev_ws, ev_bytes, &sweeps, s));
-  hipLaunchKernelGGL(scale_cols_sqrt_kernel, dim3(grid1d(c2)), dim3(256), 0, s, Lt, chi, chi, w2);
-  NDMPS_LAUNCH_CHECK();
+  if (!g2_chol) {
+    bool g2_direct = direct;
+    if (g2_direct) {
+      NDMPS_TRY(direct_values(G2, Lt, w2));
+      NDMPS_TRY(direct_vectors(chi, g2_direct));
+    }
+    if (!g2_direct) NDMPS_TRY(ndmps_syevj_f64(G2, chi, Lt, w2, ev_ws, ev_bytes, &sweeps, s));
+    hipLaunchKernelGGL(scale_cols_sqrt_kernel, dim3(grid1d(c2)), dim3(256), 0, s, Lt, chi, chi, w2);
+    NDMPS_LAUNCH_CHECK();
+  }
   NDMPS_TRY(ndmps_dgemm(0, 0, chi, chi, chi, G1, chi, Lt, chi, tmp, chi, s));
   NDMPS_TRY(ndmps_dgemm(1, 0, chi, chi, chi, Lt, chi, tmp, chi, H, chi, s));
   std::vector<double> sv(chi);

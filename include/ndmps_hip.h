@@ -252,6 +252,11 @@ int64_t ndmps_syevd_topk_workspace_bytes(int64_t n_max, int batch, int64_t k_max
 /* byte offset, inside the workspace, of 16 int64 wall-clock marks (100 MHz) per matrix left by the vectors
  * phase (profiling aid, tools/trd_probe.py) */
 int64_t ndmps_syevd_topk_stamps_offset(int64_t n_max, int batch, int64_t k_max);
+/* Cholesky factor S = L L^T of a symmetric positive definite matrix (lower triangle read, L with zeros above written in
+ * place; blocked, fp64 MFMA): the square root compress() needs of G2 = T2 T2^T (core/ndmps.py:104-106; quimb takes an LQ of
+ * T2 there).  d_scratch: ndmps_potrf_scratch_elems(n) doubles.  Synchronises; *h_status = 1: not positive definite. */
+int64_t ndmps_potrf_scratch_elems(int64_t n);
+int ndmps_potrf_lower_f64(double* d_S, int64_t n, double* d_scratch, int* h_status, ndmps_stream_t stream);
 int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t stride_G, const int64_t* h_n,
                                 double* d_V, int64_t stride_V, double* d_w, int64_t stride_w,
                                 int64_t k_max, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);

@@ -877,6 +877,31 @@ def test_direct_solver_all_vectors_of_degenerate_spectra():
         _check_topk(g, w, v, k, tol_scale=4.0)
 
 
+@pytest.mark.parametrize("n", [1, 40, 64, 130, 512, 1000])
+def test_blocked_cholesky_against_numpy(n):
+    """ndmps_potrf_lower_f64 (the square root compress() takes of G2 = T2 T2^T): the factor against numpy's, zeros above
+    the diagonal, the breakdown flag on a matrix that is not positive definite."""
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n + 3, n)) * np.logspace(0, -3, n)[None, :]
+    g = a.T @ a + 1e-9 * np.eye(n)
+    s = dev(g.copy())
+    scratch = torch.empty(int(lib.ndmps_potrf_scratch_elems(n)), dtype=torch.float64, device=DEV)
+    status = C.c_int(-1)
+    _lib.check(lib.ndmps_potrf_lower_f64(s.data_ptr(), n, scratch.data_ptr(), C.byref(status), sp()))
+    assert status.value == 0
+    got, want = s.cpu().numpy(), np.linalg.cholesky(g)
+    assert np.all(np.triu(got, 1) == 0.0)
+    assert np.abs(got @ got.T - g).max() <= 4e-15 * max(n, 16) * np.abs(g).max()
+    assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+    if n >= 40:
+        bad = g.copy()
+        bad[n // 2, n // 2] = -1.0
+        s = dev(bad)
+        _lib.check(lib.ndmps_potrf_lower_f64(s.data_ptr(), n, scratch.data_ptr(), C.byref(status), sp()))
+        assert status.value == 1
+
+
 def test_topk_solver_volume_gram_matrices_with_noise_floor_clusters():
     """The matrices the sweep meets: Gram matrices of the chi-capped unfoldings of a noisy volume, a few large
     eigenvalues over a floor of ~n near-equal ones (gaps ~1e-9 of the largest).  The kept subspace must agree
