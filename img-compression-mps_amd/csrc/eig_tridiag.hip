@@ -2189,7 +2189,7 @@ struct TrdLayout {
   int64_t n_max, lda, kp;
   int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_mu, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
   int64_t off_pv, off_pw, off_ypart, off_spart, off_ucol, off_napart, pnl_blocks, pnl_tiles;
-  int64_t off_ws, off_wlinv, off_wgram, kw, wgram_bytes;  // more than kMaxK vectors (eig_wide.inc)
+  int64_t off_ws, off_wlinv, off_wgram, off_wt, wt_stride, kw, wgram_bytes;  // more than kMaxK vectors (eig_wide.inc)
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -2251,6 +2251,8 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_ws = take(l.kw * l.kw * 8);
   l.off_wlinv = take(l.kw * l.kw * 8);
   l.off_wgram = take(l.wgram_bytes);
+  l.wt_stride = l.kw ? ndmps::ceil_div(n_max, kBwB) * kBwB * kBwB : 0;  // T factors of the blocked back-transformation
+  l.off_wt = take(batch * l.wt_stride * 8);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -2812,6 +2814,17 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
     hipLaunchKernelGGL(trd_ortho_blocks_kernel, dim3(1, B), dim3(512), (size_t)3 * 64 * 65 * 8, s, desc, w);
   else
     hipLaunchKernelGGL(trd_ortho_kernel<false>, dim3(1, B), dim3(512), (size_t)k16 * (k16 + 1) * 8, s, desc, w);
+  if (w.kp > kMaxK && !getenv("NDMPS_BACK_NARROW")) {
+    // many columns: the reflectors in blocks of 64 on the MFMA, one workgroup per 16 columns (eig_wide.inc)
+    double* Tw = (double*)((char*)d_ws + wide_layout->off_wt);
+    hipLaunchKernelGGL(back_wide_t_kernel, dim3((unsigned)ndmps::ceil_div(std::max<int64_t>(n_max - 1, 1), kBwB), B), dim3(256), 0, s,
+                       (const TrdDesc*)desc, w, Tw, wide_layout->wt_stride);
+    hipLaunchKernelGGL(back_wide_kernel, dim3((unsigned)ndmps::ceil_div(kk, kBwC), B), dim3(64 * kBwWaves), 0, s, (const TrdDesc*)desc, w,
+                       (const double*)Tw, wide_layout->wt_stride);
+    ndmps::span_end(vec_span, s, ndmps::kSpanEigenVectors, 4, 0);
+    NDMPS_LAUNCH_CHECK();
+    return NDMPS_OK;
+  }
   const int bw = route_load(w.A, band_width_for(n_max));
   if (bw) {  // eigenvectors of T -> eigenvectors of the band matrix: the bulge chase's reflectors, sweeps in reverse
     const dim3 grid((unsigned)ndmps::ceil_div(std::min<int64_t>(k16, w.kp), 32), B);
