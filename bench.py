@@ -310,12 +310,28 @@ class ProfiledRegion:
                 self.lib = None
 
     def resume(self):
+        self.t0 = self.clocks()
         if self.lib is not None:
             self.lib.roctxProfilerResume(0)
 
     def pause(self):
+        self.t1 = self.clocks()
         if self.lib is not None:
             self.lib.roctxProfilerPause(0)
+
+    @staticmethod
+    def clocks():
+        out = {}
+        for name in ("CLOCK_MONOTONIC", "CLOCK_BOOTTIME", "CLOCK_REALTIME", "CLOCK_MONOTONIC_RAW"):
+            if hasattr(time, name):
+                out[name] = time.clock_gettime_ns(getattr(time, name))
+        return out
+
+    def window(self):
+        """The timed region on the host clocks a profiler may stamp its kernels with: tools/prof_db.py --region keeps the
+        dispatches that start inside it (rocprofv3 --selected-regions recorded nothing for launches from worker threads)."""
+        t0, t1 = getattr(self, "t0", {}), getattr(self, "t1", {})
+        return {k: [t0[k], t1[k]] for k in t0 if k in t1}
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -543,6 +559,7 @@ def run_cubes(ctx):
     line["roofline"] = roofline
     line["stages"] = stages
     line["team_fallbacks"] = int(lib.ndmps_syevd_topk_team_fallbacks())
+    line["timed_region_clock_ns"] = region.window()
 
     if not args.skip_single and rank == 0:
         extras_cubes(ctx, line, xs, x, shape, n_vox, group_step, single_step, ms_per_step)
@@ -779,6 +796,7 @@ def run_tensor(ctx):
                          f"n x n fp64 Gram matrix per sharded site ({args.backend}), the replicated tail of the sweep on every rank")})
     line["roofline"] = roofline
     line["team_fallbacks"] = int(lib.ndmps_syevd_topk_team_fallbacks())
+    line["timed_region_clock_ns"] = region.window()
     if world == 1 and not args.skip_single:
         t = {}
         for name, fn in (("encode", lambda: NDMPS.from_tensor(xb, mode=job["mode"], max_bond=chi, dtype=torch.bfloat16)),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 results database (rocpd sqlite, the default output of rocprofv3 7.x): per-kernel
 totals and, optionally, the timeline (durations and gaps) around the middle launch of one kernel.
-usage: python tools/prof_db.py path/to/x_results.db [top_n] [--gaps KERNEL_SUBSTR [count]]"""
+usage: python tools/prof_db.py path/to/x_results.db [top_n] [--gaps KERNEL_SUBSTR [count]] [--region bench_line.json]"""
 import sqlite3
 import sys
 
@@ -11,6 +11,23 @@ def main():
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     name = "name" if "name" in cols else "kernel_name"
     rows = con.execute(f"select {name}, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
+    if "--region" in sys.argv:
+        # keep the dispatches that start inside bench.py's timed region (its JSON line carries the region on several host
+        # clocks: the one whose window overlaps the trace is the profiler's)
+        import json
+        with open(sys.argv[sys.argv.index("--region") + 1]) as fh:
+            line = json.loads(fh.read().strip().splitlines()[-1])
+        lo_all, hi_all = rows[0][1], rows[-1][2]
+        kept = None
+        for clock, (a, b) in line.get("timed_region_clock_ns", {}).items():
+            if a < hi_all and b > lo_all:
+                kept = [r for r in rows if a <= r[1] <= b]
+                print(f"# dispatches inside the timed region ({clock}: {(b - a) / 1e6:.1f} ms): {len(kept)} of {len(rows)}")
+                break
+        if kept is None:
+            print("# no clock of the timed region overlaps the trace: every dispatch is listed")
+        else:
+            rows = kept
     top = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 25
     agg = {}
     for n, s, e, *_ in rows:
