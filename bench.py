@@ -292,22 +292,14 @@ def roofline_of(slots, steps, eig_order=None):
 
 
 class ProfiledRegion:
-    """rocprofv3 --selected-regions collects only between roctxProfilerResume and roctxProfilerPause: the timed loop
-    brackets itself, so the committed kernel summaries list the timed region and not the volume generator or the
-    reference points behind it.  Without the profiler (or its library) the calls do nothing."""
+    """The timed region on the host clocks a profiler stamps its kernels with: the bench line carries the window
+    (`timed_region_clock_ns`) and tools/prof_db.py --region keeps the dispatches that start inside it, so the committed
+    kernel summaries list the timed region and not the volume generator, the warm-up or the reference points.
+    (rocprofv3 --selected-regions with roctxProfilerResume / Pause recorded nothing for launches from worker threads,
+    and merely loading the roctx library made every eager launch slower: config 5, 8 000 launches per step, 66.5 -> 75 ms.)"""
 
     def __init__(self):
-        import ctypes as C
-
         self.lib = None
-        for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
-            try:
-                self.lib = C.CDLL(name)
-                self.lib.roctxProfilerResume.argtypes = [C.c_uint64]
-                self.lib.roctxProfilerPause.argtypes = [C.c_uint64]
-                break
-            except (OSError, AttributeError):
-                self.lib = None
 
     def resume(self):
         self.t0 = self.clocks()
@@ -809,6 +801,40 @@ def run_tensor(ctx):
             torch.cuda.synchronize()
             t[name + "_ms"] = (time.perf_counter() - t0) / 3 * 1e3
         line["stages"] = t
+    if rank == 0 and world == 1 and not args.skip_single:
+        # ---- what bf16 costs, and where: bf16 everywhere (the storage type of `value`: volume, carried matrices, cores,
+        # reconstruction) against bf16 volume / cores / reconstruction with the SWEEP in fp32 (carry_dtype: the volume is
+        # widened once, nothing is rounded between the sites), both against the NumPy oracle on the bf16-rounded sample
+        # and timed at full size
+        from oracle.metrics import compute_ssim_by_dim as ssim_host
+
+        s_shape = (64, 64, 32, 64)
+        ref_b, rec_ref_b, _cpu, _thr, s_xb = oracle_sample(s_shape, job["first_seed"], chi, job["mode"], bf16=True)
+        x64 = s_xb.astype(np.float64)
+        ssim_ref = ssim_host(x64, rec_ref_b)
+        price = {"sample": "64 x 64 x 32 x 64 of the same generator rounded to bf16, chi = 128 binding on two bonds; ms at full size"}
+        sx = torch.from_numpy(s_xb).to(device).to(torch.bfloat16)
+        for name, carry in (("bf16_everywhere", None), ("bf16_storage_fp32_sweep", torch.float32)):
+            so = NDMPS.from_tensor(sx, mode=job["mode"], max_bond=chi, dtype=torch.bfloat16, carry_dtype=carry)
+            srec = so.to_tensor(as_torch=True).float().cpu().numpy().astype(np.float64)
+
+            def full_step():
+                o = NDMPS.from_tensor(xb, mode=job["mode"], max_bond=chi, dtype=torch.bfloat16, carry_dtype=carry)
+                return o.to_tensor(as_torch=True)
+
+            full_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                full_step()
+            torch.cuda.synchronize()
+            ms_full = (time.perf_counter() - t0) / 2 * 1e3
+            price[name] = {"ssim_gap": abs(ssim_host(x64, srec) - ssim_ref),
+                           "rel_frobenius_vs_oracle": float(np.linalg.norm(srec - rec_ref_b) / np.linalg.norm(rec_ref_b)),
+                           "bonds_equal": so.bond_sizes() == ref_b.bond_sizes(), "ms_per_step_full_size": ms_full}
+        price["default"] = ("bf16 everywhere: the error is the rounding of the volume, the cores and the reconstruction to bf16; "
+                            "an fp32 sweep in between changes neither figure and costs the fp32 copy of the volume")
+        line["bf16_price"] = price
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: the same recipe at 64 x 64 x 32 x 64 (1/32 of the voxels; site dims [64, 16, 16, 16, 32],
         # exact bonds [64, 1024, 512, 32]: chi = 128 binds on two bonds, the order-2048 eigenproblem is on the path)

@@ -331,7 +331,7 @@ class NDMPS:
     # ---------------------------------------------------------------------- encode
     @classmethod
     def from_tensor(cls, tensor, norm: bool = False, mode: str = "Std", max_bond=None,
-                    cutoff: float = 1e-10, device=None, dtype=None, sweep_from: str = "right") -> "NDMPS":
+                    cutoff: float = 1e-10, device=None, dtype=None, sweep_from: str = "right", carry_dtype=None) -> "NDMPS":
         """
         Create an NDMPS instance from a tensor with encoding and optional normalization.
 
@@ -344,7 +344,14 @@ class NDMPS:
             (the reference's own element type; see from_tensors).
         sweep_from : "right" (default) or "left": which end quimb's ``from_dense`` (ndmps.py:74) starts from; see
             from_tensors.
+        carry_dtype : element type of the SWEEP when it differs from the storage type ``dtype``: with
+            ``dtype=torch.bfloat16, carry_dtype=torch.float32`` the volume is widened to fp32, the carried matrices of the
+            sweep are fp32 (no bf16 rounding between the sites) and only the finished cores are rounded to bf16
+            (``astype``); reconstruction then runs in bf16 as for any bf16 object.
         """
+        if carry_dtype is not None and dtype is not None and carry_dtype != dtype:
+            return cls.from_tensors([tensor], norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff, device=device,
+                                    dtype=carry_dtype, sweep_from=sweep_from)[0].astype(dtype)
         return cls.from_tensors([tensor], norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff,
                                 device=device, dtype=dtype, sweep_from=sweep_from)[0]
 
@@ -648,6 +655,22 @@ class NDMPS:
         return objs
 
     # ----------------------------------------------------------------- bookkeeping
+    def astype(self, dtype):
+        """A copy of this object with its cores stored as ``dtype`` (torch.float32, torch.bfloat16 or torch.float64): the
+        cores are rounded once, ``boundary_list`` and ``norm_value`` are those of the rounded cores.  No counterpart in the
+        reference (it has one element type, ndmps.py:56)."""
+        torch = _torch()
+        if dtype not in (torch.float32, torch.bfloat16, torch.float64):
+            raise ValueError("storage dtype must be torch.float32, torch.bfloat16 or torch.float64")
+        from .mps import DeviceMPS
+
+        out = NDMPS(DeviceMPS([c.to(dtype).contiguous() for c in self.mps.cores]), self.qubit_size, None, None, self.norm, None,
+                    self.mode, self.dim)
+        out._shape = self._shape
+        out.update_boundary_list()
+        out.update_norm()
+        return out
+
     def update_boundary_list(self):
         """Recompute min/max boundaries for each MPS tensor."""
         self.boundary_list = np.array([list(v) for v in _ft.minmax_many(self.mps.cores)])

@@ -2419,7 +2419,7 @@ int64_t panel_min_order() {
   return std::max<int64_t>(v, 513);  // the workspace holds the panel arrays from order 513 on
 }
 
-// ---- launch sequence of the panel-blocked reduction, eager or as a cached graph
+// ---- launch sequence of the panel-blocked reduction, eager (default) or as a cached graph
 struct PnlLaunch {
   int kind;  // 0 pnl_vec_kernel, 1 pnl_update_kernel, 2 pnl_symv_kernel
   unsigned grid_x;
@@ -2447,7 +2447,11 @@ int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, in
   int n_uniform = (int)h_n[0];  // equal orders: the kernels take the order from their arguments
   for (int b = 1; b < batch; ++b)
     if (h_n[b] != h_n[0]) n_uniform = 0;
-  if (getenv("NDMPS_TRD_PANEL_EAGER")) {
+  // Launched one by one unless NDMPS_TRD_PANEL_GRAPH is set.  The replay of a cached graph takes the same device time
+  // (the sequence is bound by the dependent launches, not by the host: 24.7 ms either way at order 2048) and only frees
+  // the host thread -- but a graph holds the workspace addresses, and instantiating one (3900 nodes) costs about a
+  // second: a caller whose workspace moves between calls would pay that every time.
+  if (!getenv("NDMPS_TRD_PANEL_GRAPH")) {
     for (const PnlLaunch& q : seq)
       hipLaunchKernelGGL(kernels[q.kind], dim3(q.grid_x, B), dim3(256), 0, s, (const TrdDesc*)desc, w, q.j, n_uniform);
     NDMPS_LAUNCH_CHECK();

@@ -814,9 +814,9 @@ def test_topk_solver_panel_blocked_reduction_degenerate_spectra(monkeypatch):
 
 
 def test_topk_solver_panel_path_against_the_column_launches(monkeypatch):
-    """The same matrices through the panel-blocked reduction, its launches issued one by one instead of replayed from
-    the cached graph (bit-identical: same kernels in the same order), and through the one-launch-per-column reduction
-    it replaces above order 512 (same eigenvalues, same kept subspace)."""
+    """The same matrices through the panel-blocked reduction, its launches issued one by one and replayed from a cached
+    graph (NDMPS_TRD_PANEL_GRAPH; bit-identical: same kernels in the same order), and through the one-launch-per-column
+    reduction it replaces from order 1536 on (same eigenvalues, same kept subspace)."""
     lib = _lib.load()
     monkeypatch.setenv("NDMPS_TRD_PANEL_MIN", "513")
     rng = np.random.default_rng(3)
@@ -826,10 +826,11 @@ def test_topk_solver_panel_path_against_the_column_launches(monkeypatch):
         mats.append(a.T @ a)
     ks = [96, 64]
     first = _topk(lib, mats, ks, k_max=128)
-    again = _topk(lib, mats, ks, k_max=128)  # replayed from the cached graph if the workspace came back at the same address
-    monkeypatch.setenv("NDMPS_TRD_PANEL_EAGER", "1")
-    eager = _topk(lib, mats, ks, k_max=128)
-    monkeypatch.delenv("NDMPS_TRD_PANEL_EAGER")
+    again = _topk(lib, mats, ks, k_max=128)
+    monkeypatch.setenv("NDMPS_TRD_PANEL_GRAPH", "1")  # the same launches replayed from a graph
+    _topk(lib, mats, ks, k_max=128)
+    eager = _topk(lib, mats, ks, k_max=128)  # replayed from the cached graph if the workspace came back at the same address
+    monkeypatch.delenv("NDMPS_TRD_PANEL_GRAPH")
     monkeypatch.setenv("NDMPS_TRD_NO_PANEL", "1")
     columns = _topk(lib, mats, ks, k_max=128)
     for g, k, (w, v), (w1, v1), (w2, v2), (w3, v3) in zip(mats, ks, first, again, eager, columns):
@@ -1306,7 +1307,7 @@ def test_bf16_volume_in_and_out():
 # Tolerance of everything below: bf16 keeps 8 significant bits, every stored value (volume, carried matrix,
 # core, chain intermediate, reconstruction) is rounded to 2^-9 relative; a reconstruction goes through ~2 L of
 # them, so results are compared at 2e-2 relative (fp32 accumulation errors are four orders smaller).
-BF16_TOL = 2e-2
+BF16_TOL = 1e-2  # twice what the 64 x 64 x 32 x 64 sample of BASELINE config 5 measures (4.8e-3 relative, bench.py bf16_price)
 
 
 @pytest.mark.parametrize("m,n,k,transB", [(128, 128, 64, 1), (1000, 130, 70, 0), (4097, 256, 128, 0), (300, 8, 8, 1),
