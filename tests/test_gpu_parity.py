@@ -1342,6 +1342,32 @@ def test_gram_bf16_is_exact_in_fp64():
         assert float((g - ref).abs().max()) <= 1e-13 * float(ref.abs().max())
 
 
+def test_bf16_and_fp32_sweep_on_a_4d_sample_with_three_capped_bonds_match_the_oracle():
+    """64 x 64 x 64 x 64 (16.8 Mvoxels: site dims 16 x 6, exact bonds [16, 256, 4096, 256, 16]) at chi = 128: the cap
+    binds on THREE bonds and three eigenproblems of order 16 x 128 = 2048 (BASELINE config 5's; the panel-blocked
+    reduction) are on the path.  bf16 storage end to end and bf16 cores behind an fp32 sweep (carry_dtype) against the
+    oracle on the bf16-rounded tensor at BF16_TOL; fp32 storage at the fp32 bar."""
+    shape, chi = (64, 64, 64, 64), 128
+    xb = torch.from_numpy(synthetic_mri(shape, seed=5)).to(DEV).to(torch.bfloat16)
+    x32 = xb.float()
+    ref = OracleNDMPS.from_tensor(x32.cpu().numpy(), max_bond=chi)
+    assert ref.bond_sizes() == [16, 128, 128, 128, 16]
+    rr = ref.to_tensor()
+    for carry in (None, torch.float32):
+        obj = NDMPS.from_tensor(xb, max_bond=chi, dtype=torch.bfloat16, carry_dtype=carry)
+        assert all(c.dtype == torch.bfloat16 for c in obj.mps.cores) and obj.bond_sizes() == ref.bond_sizes()
+        rec = obj.to_tensor(as_torch=True).double().cpu().numpy()
+        assert np.linalg.norm(rec - rr) <= BF16_TOL * np.linalg.norm(rr)
+        assert math.isclose(obj.norm_value, ref.norm_value, rel_tol=BF16_TOL)
+        if carry is None:
+            x64 = x32.double().cpu().numpy()
+            assert abs(compute_ssim_by_dim(x64, rec) - compute_ssim_by_dim(x64, rr)) <= BF16_TOL
+    obj = NDMPS.from_tensor(x32, max_bond=chi)
+    assert obj.bond_sizes() == ref.bond_sizes()
+    rec = obj.to_tensor(as_torch=True).double().cpu().numpy()
+    assert np.linalg.norm(rec - rr) <= 3e-5 * np.linalg.norm(rr)
+
+
 @pytest.mark.parametrize("shape,chi,mode", [((32, 32, 16, 24), 20, "Std"), ((64, 64, 64), 32, "Std"),
                                             ((32, 32, 16, 24), 16, "DCT"), ((48, 40, 36), 12, "Std"),
                                             ((64, 64, 32, 64), 128, "Std")], ids=str)
