@@ -476,15 +476,16 @@ class NDMPS:
             n_merge = 0 if (bf16 or f64 or os.environ.get("NDMPS_NO_FUSED_ENCODE")) else int(lib.ndmps_tt_merge_columns(L, cdims, mb))
             gather = plan.gather_tables(n_merge, device) if n_merge > 0 else None
             denses = []
+            if (norm or mode == "DCT") and bf16:
+                xs = [x.to(torch.float32) for x in xs]  # the norm / DCT kernels are fp32; rounded back to bf16 below
+            if norm:
+                # the norms of the whole group from ONE launch and one synchronisation (the reference divides volume by
+                # volume, ndmps.py:60-61; a sum-of-squares call per volume was a host round trip per volume)
+                _, sumsqs = _ft.minmax_many(xs, with_sumsq=True)
+                scale = lib.ndmps_scale_f64 if f64 else lib.ndmps_scale_f32
+                for x, ss in zip(xs, sumsqs):
+                    _lib.check(scale(x.data_ptr(), numel, 1.0 / float(np.sqrt(ss)), stream))
             for x in xs:
-                if (norm or mode == "DCT") and bf16:
-                    x = x.to(torch.float32)  # the norm / DCT kernels are fp32; rounded back to bf16 below
-                if norm:
-                    ws = torch.empty(lib.ndmps_reduce_workspace_bytes(), dtype=torch.uint8, device=device)
-                    ss = C.c_double()
-                    sumsq, scale = (lib.ndmps_sumsq_f64, lib.ndmps_scale_f64) if f64 else (lib.ndmps_sumsq_f32, lib.ndmps_scale_f32)
-                    _lib.check(sumsq(x.data_ptr(), numel, C.byref(ss), ws.data_ptr(), ws.numel(), stream))
-                    _lib.check(scale(x.data_ptr(), numel, 1.0 / float(np.sqrt(ss.value)), stream))
                 if mode == "DCT":
                     n = shape[-1]
                     y = torch.empty_like(x)

@@ -2187,7 +2187,7 @@ constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction wh
 
 struct TrdLayout {
   int64_t n_max, lda, kp;
-  int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_mu, off_bound, off_z, off_lu, off_piv, off_desc, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
+  int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_mu, off_bound, off_z, off_lu, off_piv, off_desc, off_desc2, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
   int64_t off_pv, off_pw, off_ypart, off_spart, off_ucol, off_napart, pnl_blocks, pnl_tiles;
   int64_t off_ws, off_wlinv, off_wgram, off_wt, wt_stride, kw, wgram_bytes;  // more than kMaxK vectors (eig_wide.inc)
 };
@@ -2220,6 +2220,7 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_lu = take(batch * 4 * n_max * l.kp * 8);
   l.off_piv = take(batch * n_max * l.kp);
   l.off_desc = take(batch * (int64_t)sizeof(TrdDesc));
+  l.off_desc2 = take(batch * (int64_t)sizeof(TrdDesc));  // the trailing blocks the resident kernel finishes behind the panels
   l.off_stamps = take(batch * 16 * 8);
   l.t_stride = (n_max + 8) * 4;  // groups of WYB reflectors, WYB^2 doubles each, WYB <= 4
   l.off_tw = take(batch * l.t_stride * 8);
@@ -2412,10 +2413,12 @@ int trd_check_sizes(int batch, const int64_t* h_n, int64_t& n_max) {
 // Smallest order that takes the panel-blocked reduction.  A dependent launch costs ~5 us here whatever it does: two of
 // them per column (10.7 us at any order) beat the column launch -- one launch, but the trailing matrix read and
 // written, 7.6 us per column at order 1024, 13.5 at 2048, 35 at 4096 -- from about order 1500 on
-// (profiles/r04_f_panel_probe.txt: 9.6 vs 6.8 ms at 1024, 22.2 vs 26.2 at 2048, 63 vs 140 at 4096).
-int64_t panel_min_order() {
+// (profiles/r04_f_panel_probe.txt: 9.6 vs 6.8 ms at 1024, 22.2 vs 26.2 at 2048, 63 vs 140 at 4096).  When the last
+// 512 columns go to the resident kernel (`hybrid` below) the break-even is order 1024 for one matrix (6.9 vs 6.8 ms)
+// and far below for a batch (8 of order 1024: 8.8 vs 12.6 ms; profiles/r04_w_panel_probe.txt).
+int64_t panel_min_order(bool hybrid) {
   const char* e = getenv("NDMPS_TRD_PANEL_MIN");
-  const int64_t v = e ? atoll(e) : 1536;
+  const int64_t v = e ? atoll(e) : hybrid ? 1024 : 1536;
   return std::max<int64_t>(v, 513);  // the workspace holds the panel arrays from order 513 on
 }
 
@@ -2430,7 +2433,7 @@ struct PnlGraph {
   const void* desc;  // the descriptors live in the caller's workspace: workspace address, layout and sizes name a graph
   const void* a;
   int64_t n_max;
-  int batch;
+  int batch, tail_cols;
   std::vector<int64_t> sizes;
   hipGraph_t graph;
   hipGraphExec_t exec;
@@ -2438,12 +2441,12 @@ struct PnlGraph {
 };
 constexpr size_t kPnlGraphs = 8;  // least recently used beyond that is destroyed
 
-int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, int64_t n_max, TrdDesc* desc, const TrdWork& w,
-            hipStream_t s) {
+int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, int64_t n_max, int tail_cols, TrdDesc* desc,
+            const TrdWork& w, hipStream_t s) {
   const unsigned B = (unsigned)batch;
-  void (*const vec)(const TrdDesc*, TrdWork, int, int) =
+  void (*const vec)(const TrdDesc*, TrdWork, int, int, int) =
       n_max <= 1024 ? pnl_vec_kernel<4> : (n_max <= 2048 ? pnl_vec_kernel<8> : pnl_vec_kernel<16>);
-  void (*const kernels[3])(const TrdDesc*, TrdWork, int, int) = {vec, pnl_update_kernel, pnl_symv_kernel};
+  void (*const kernels[3])(const TrdDesc*, TrdWork, int, int, int) = {vec, pnl_update_kernel, pnl_symv_kernel};
   int n_uniform = (int)h_n[0];  // equal orders: the kernels take the order from their arguments
   for (int b = 1; b < batch; ++b)
     if (h_n[b] != h_n[0]) n_uniform = 0;
@@ -2453,7 +2456,7 @@ int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, in
   // second: a caller whose workspace moves between calls would pay that every time.
   if (!getenv("NDMPS_TRD_PANEL_GRAPH")) {
     for (const PnlLaunch& q : seq)
-      hipLaunchKernelGGL(kernels[q.kind], dim3(q.grid_x, B), dim3(256), 0, s, (const TrdDesc*)desc, w, q.j, n_uniform);
+      hipLaunchKernelGGL(kernels[q.kind], dim3(q.grid_x, B), dim3(256), 0, s, (const TrdDesc*)desc, w, q.j, n_uniform, tail_cols);
     NDMPS_LAUNCH_CHECK();
     return NDMPS_OK;
   }
@@ -2466,7 +2469,7 @@ int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, in
   {
     std::lock_guard<std::mutex> lock(mu);
     for (PnlGraph& g : cache)
-      if (g.dev == dev && g.desc == desc && g.a == w.A && g.n_max == w.n_max && g.batch == batch &&
+      if (g.dev == dev && g.desc == desc && g.a == w.A && g.n_max == w.n_max && g.batch == batch && g.tail_cols == tail_cols &&
           std::equal(g.sizes.begin(), g.sizes.end(), h_n)) {
         g.used = ++clock;
         exec = g.exec;
@@ -2474,15 +2477,15 @@ int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, in
       }
     if (!exec) {
       PnlGraph g;
-      g.dev = dev, g.desc = desc, g.a = w.A, g.n_max = w.n_max, g.batch = batch;
+      g.dev = dev, g.desc = desc, g.a = w.A, g.n_max = w.n_max, g.batch = batch, g.tail_cols = tail_cols;
       g.sizes.assign(h_n, h_n + batch);
       NDMPS_CHECK_HIP(hipGraphCreate(&g.graph, 0));
       hipGraphNode_t prev = nullptr;
       for (const PnlLaunch& q : seq) {
         const TrdDesc* d_arg = desc;
         TrdWork w_arg = w;
-        int j_arg = q.j, n_arg = n_uniform;
-        void* args[4] = {&d_arg, &w_arg, &j_arg, &n_arg};
+        int j_arg = q.j, n_arg = n_uniform, t_arg = tail_cols;
+        void* args[5] = {&d_arg, &w_arg, &j_arg, &n_arg, &t_arg};
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
         kp.func = reinterpret_cast<void*>(kernels[q.kind]);
@@ -2520,6 +2523,63 @@ int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, in
     }
     NDMPS_CHECK_HIP(hipGraphLaunch(exec, s));  // under the lock: an entry is never destroyed between look-up and launch
   }
+  return NDMPS_OK;
+}
+
+// Resident tridiagonalisation (trd_team_kernel and variants) of `batch` matrices of order <= 512 named by `desc`, all
+// columns up to the last kTail in one launch (or a few, by the resident slots); takes the device-side turn.  Used for
+// orders <= 512 and for the last 512 columns behind the panel-blocked reduction (a view of the workspace).
+int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStream_t s) {
+    // a launch never holds more workgroups than the device keeps resident at once: no team then depends on the
+    // order in which the dispatcher places workgroups (larger batches go in several launches)
+    int slots = 0;
+    NDMPS_TRY(team_slots(slots));
+    // one to four matrices: 8-column blocks (64 workgroups per order-512 matrix, one per CU)
+    const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= slots && !getenv("NDMPS_TRD_TEAM_WIDE");
+    // opt-in, batches that fill more than half the slots (17 order-512 matrices and more): half storage (eig_sym.inc),
+    // 8 workgroups per order-512 matrix -- a group of 32 takes one workgroup slot per CU and shares the GPU with the
+    // other group's reduction or kernels
+    const char* sym_env = getenv("NDMPS_TRD_SYM");
+    const bool sym = !narrow_team && n_max <= 512 && (sym_env ? atoi(sym_env) != 0 : kSymDefault) &&
+                     (int64_t)batch * ndmps::ceil_div(n_max, 32) > slots / 2;
+    w.tail_lower = sym ? 1 : 0;
+    const int team_size = sym ? (int)ndmps::ceil_div(ndmps::ceil_div(n_max, 32), 2) : (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
+    const int per_launch = std::max(1, slots / team_size);
+    const char* xcd_env = getenv("NDMPS_TRD_XCD");
+    const bool xcd_placed = xcd_env ? atoi(xcd_env) != 0 : kTeamXcdDefault;
+    int inject = g_inject_abort.load();
+    while (inject > 0 && !g_inject_abort.compare_exchange_weak(inject, inject - 1)) {
+    }
+    if (inject > 0) {
+      hipLaunchKernelGGL(trd_inject_abort_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch);
+    } else
+    NDMPS_TRY(team_launch(s, [&]() {
+      static std::atomic<unsigned> epoch_counter{1};
+      // exchange without meetings (tagged records) while every workgroup has a CU's SIMDs to itself: 3-4 % faster
+      // for up to 16 order-512 matrices; with two workgroups per CU the polls of the waiting one get in the way of
+      // the working one and the counter is as fast (2.49 vs 2.53 ms for 32 matrices).  Environment: A/B.
+      const bool tagged = getenv("NDMPS_TRD_TEAM_COUNTER") ? false
+                          : getenv("NDMPS_TRD_TEAM_TAGGED") ? true
+                                                            : (int64_t)std::min(per_launch, batch) * team_size <= slots / 2;
+      for (int b0 = 0; b0 < batch; b0 += per_launch) {
+        const unsigned epoch = epoch_counter.fetch_add(1);
+        const int count = std::min(per_launch, batch - b0);
+        TrdWork wl = w;
+        dim3 grid((unsigned)team_size, (unsigned)count);
+        if (xcd_placed) {
+          wl.xcd_team = team_size;
+          wl.xcd_count = count;
+          // early leavers (low block-columns) beside late ones: needs whole teams on either side of every 32nd workgroup
+          const bool pairable = 32 % team_size == 0 || team_size % 32 == 0;
+          wl.xcd_pair = sym || !pairable ? 0 : getenv("NDMPS_TRD_PAIR") ? atoi(getenv("NDMPS_TRD_PAIR")) : 1;
+          grid = dim3((unsigned)(team_size * count));
+        }
+        if (sym) hipLaunchKernelGGL(trd_sym_kernel, grid, dim3(256), 0, s, desc, wl, b0);
+        else if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
+        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
+        else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
+      }
+    }, (int64_t)std::min(per_launch, batch) * team_size <= slots / 2));  // half a turn only for what fits half the slots
   return NDMPS_OK;
 }
 
@@ -2585,78 +2645,42 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
     NDMPS_LAUNCH_CHECK();
     return NDMPS_OK;
   }
+  // Hand-over of a panel-blocked reduction to the resident kernel for its last 512 columns: a column costs that kernel
+  // ~4 us (one exchange inside a team of workgroups) against ~11 us of the two launches.  Needs one order for the whole
+  // batch (the view below is one offset into the workspace), an even one (the parity of a column selects its exchange
+  // buffer on both sides), the resident launches switched on, and every team of the batch resident in one launch.
+  constexpr int kHybrid = 512;
+  bool hybrid = !team && n_max - kHybrid >= kPnlTB && n_max % 2 == 0 && !g_team_off && !getenv("NDMPS_TRD_NO_TEAM") &&
+                !getenv("NDMPS_TRD_NO_HYBRID");
+  for (int b = 0; b < batch && hybrid; ++b) hybrid = h_n[b] == n_max;
+  if (hybrid) {
+    int slots = 0;
+    NDMPS_TRY(team_slots(slots));
+    hybrid = (int64_t)batch * (kHybrid / 8) <= slots;
+  }
   void* span = ndmps::span_begin(s);
   int64_t span_bytes = 0;  // algorithmic: every trailing element read once and written once per column
   if (team) {
-    // a launch never holds more workgroups than the device keeps resident at once: no team then depends on the
-    // order in which the dispatcher places workgroups (larger batches go in several launches)
-    int slots = 0;
-    NDMPS_TRY(team_slots(slots));
-    // one to four matrices: 8-column blocks (64 workgroups per order-512 matrix, one per CU)
-    const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= slots && !getenv("NDMPS_TRD_TEAM_WIDE");
-    // opt-in, batches that fill more than half the slots (17 order-512 matrices and more): half storage (eig_sym.inc),
-    // 8 workgroups per order-512 matrix -- a group of 32 takes one workgroup slot per CU and shares the GPU with the
-    // other group's reduction or kernels
-    const char* sym_env = getenv("NDMPS_TRD_SYM");
-    const bool sym = !narrow_team && n_max <= 512 && (sym_env ? atoi(sym_env) != 0 : kSymDefault) &&
-                     (int64_t)batch * ndmps::ceil_div(n_max, 32) > slots / 2;
-    w.tail_lower = sym ? 1 : 0;
-    const int team_size = sym ? (int)ndmps::ceil_div(ndmps::ceil_div(n_max, 32), 2) : (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
-    const int per_launch = std::max(1, slots / team_size);
-    const char* xcd_env = getenv("NDMPS_TRD_XCD");
-    const bool xcd_placed = xcd_env ? atoi(xcd_env) != 0 : kTeamXcdDefault;
-    int inject = g_inject_abort.load();
-    while (inject > 0 && !g_inject_abort.compare_exchange_weak(inject, inject - 1)) {
-    }
-    if (inject > 0) {
-      hipLaunchKernelGGL(trd_inject_abort_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch);
-    } else
-    NDMPS_TRY(team_launch(s, [&]() {
-      static std::atomic<unsigned> epoch_counter{1};
-      // exchange without meetings (tagged records) while every workgroup has a CU's SIMDs to itself: 3-4 % faster
-      // for up to 16 order-512 matrices; with two workgroups per CU the polls of the waiting one get in the way of
-      // the working one and the counter is as fast (2.49 vs 2.53 ms for 32 matrices).  Environment: A/B.
-      const bool tagged = getenv("NDMPS_TRD_TEAM_COUNTER") ? false
-                          : getenv("NDMPS_TRD_TEAM_TAGGED") ? true
-                                                            : (int64_t)std::min(per_launch, batch) * team_size <= slots / 2;
-      for (int b0 = 0; b0 < batch; b0 += per_launch) {
-        const unsigned epoch = epoch_counter.fetch_add(1);
-        const int count = std::min(per_launch, batch - b0);
-        TrdWork wl = w;
-        dim3 grid((unsigned)team_size, (unsigned)count);
-        if (xcd_placed) {
-          wl.xcd_team = team_size;
-          wl.xcd_count = count;
-          // early leavers (low block-columns) beside late ones: needs whole teams on either side of every 32nd workgroup
-          const bool pairable = 32 % team_size == 0 || team_size % 32 == 0;
-          wl.xcd_pair = sym || !pairable ? 0 : getenv("NDMPS_TRD_PAIR") ? atoi(getenv("NDMPS_TRD_PAIR")) : 1;
-          grid = dim3((unsigned)(team_size * count));
-        }
-        if (sym) hipLaunchKernelGGL(trd_sym_kernel, grid, dim3(256), 0, s, desc, wl, b0);
-        else if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
-        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
-        else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
-      }
-    }, (int64_t)std::min(per_launch, batch) * team_size <= slots / 2));  // half a turn only for what fits half the slots
+    NDMPS_TRY(trd_team_reduce(batch, n_max, desc, w, s));
     // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
     for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
     ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, span_bytes);
-  } else if (n_max >= panel_min_order() && !getenv("NDMPS_TRD_NO_PANEL")) {
+  } else if (n_max >= panel_min_order(hybrid) && !getenv("NDMPS_TRD_NO_PANEL")) {
     // panel-blocked reduction (eig_panel.inc): two launches per column, one update per panel of kPnlNB columns
-    w.tail_lower = 1;
     NDMPS_CHECK_HIP(hipMemsetAsync(w.Vh, 0, (size_t)batch * n_max * l.lda * 8, s));
     NDMPS_CHECK_HIP(hipMemsetAsync(w.pv, 0, (size_t)batch * n_max * kPnlNB * 8, s));
     NDMPS_CHECK_HIP(hipMemsetAsync(w.pw, 0, (size_t)batch * n_max * kPnlNB * 8, s));
-    const int J_max = (int)n_max - kTail;
+    const int tail_cols = hybrid ? kHybrid : kTail;
+    w.tail_lower = hybrid ? 0 : 1;
+    const int J_max = (int)n_max - tail_cols;
     std::vector<char> ends((size_t)J_max + 1, 0);
-    for (int b = 0; b < batch; ++b) ends[(size_t)std::max<int64_t>(h_n[b] - kTail, 0)] = 1;
+    for (int b = 0; b < batch; ++b) ends[(size_t)std::max<int64_t>(h_n[b] - tail_cols, 0)] = 1;
     const int nbm = (int)l.pnl_blocks;
     auto tiles = [&](int first_col) {
       const int nblk = nbm - first_col / kPnlTB;
       return (unsigned)(nblk * (nblk + 1) / 2);
     };
-    // the launch sequence: (kernel, grid.x, column); replayed from a cached graph unless NDMPS_TRD_PANEL_EAGER is set
-    // (the host enqueues ~3.5 us per launch; the graph leaves the kernel boundaries)
+    // the launch sequence: (kernel, grid.x, column)
     std::vector<PnlLaunch> seq;
     seq.reserve((size_t)2 * J_max + J_max / kPnlNB + 4);
     for (int j = 0; j <= J_max; ++j) {
@@ -2665,11 +2689,31 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
       if (j < J_max) seq.push_back({2, tiles(j + 1), j});
       if (span)
         for (int b = 0; b < batch; ++b)
-          if (j < h_n[b] - kTail) span_bytes += 4 * (h_n[b] - j - 1) * (h_n[b] - j - 1);  // the lower half, read once
+          if (j < h_n[b] - tail_cols) span_bytes += 4 * (h_n[b] - j - 1) * (h_n[b] - j - 1);  // the lower half, read once
     }
-    NDMPS_TRY(pnl_run(seq, batch, h_n, n_max, desc, w, s));
-    // nothing is pending when the tail kernel takes over: its update of "the last column launch" must vanish
-    NDMPS_CHECK_HIP(hipMemsetAsync(w.y, 0, (size_t)batch * 2 * l.lda * 8, s));
+    NDMPS_TRY(pnl_run(seq, batch, h_n, n_max, tail_cols, desc, w, s));
+    if (hybrid) {
+      // the trailing 512 x 512 block in full storage, then the resident kernel on a VIEW of the workspace: matrix,
+      // reflector rows, T's diagonals and the pending product of its last column all sit at offset J0 of the big
+      // arrays, so the tail kernel finds everything where the column launches would have left it
+      const int64_t J0 = n_max - kHybrid;
+      TrdDesc* sub = (TrdDesc*)((char*)w_in.A - l.off_a + l.off_desc2);
+      hipLaunchKernelGGL(pnl_mirror_kernel, dim3(256, B), dim3(256), 0, s, w, (int)n_max, kHybrid);
+      hipLaunchKernelGGL(pnl_subdesc_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, (const TrdDesc*)desc, sub, batch, kHybrid);
+      TrdWork v = w;
+      v.A = w.A + J0 * l.lda + J0;
+      v.Vh = w.Vh + J0 * l.lda + J0;
+      v.y = w.y + J0;
+      v.tau = w.tau + J0;
+      v.d = w.d + J0;
+      v.e = w.e + J0;
+      NDMPS_TRY(trd_team_reduce(batch, kHybrid, sub, v, s));
+      hipLaunchKernelGGL(pnl_substatus_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, (const TrdDesc*)sub, batch);
+      w.tail_lower = 0;  // the resident kernel hands the trailing block over in full storage
+    } else {
+      // nothing is pending when the tail kernel takes over: its update of "the last column launch" must vanish
+      NDMPS_CHECK_HIP(hipMemsetAsync(w.y, 0, (size_t)batch * 2 * l.lda * 8, s));
+    }
     ndmps::span_end(span, s, ndmps::kSpanTridiagPanel, (int64_t)seq.size(), span_bytes);
   } else {
     for (int j = 0; j < n_max - kTail; ++j) {

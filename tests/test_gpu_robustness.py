@@ -78,6 +78,52 @@ def test_solver_recovers_from_an_aborted_resident_launch(lib):
     assert int(lib.ndmps_syevd_topk_team_fallbacks()) == before + 1
 
 
+def test_solver_recovers_when_the_resident_end_of_a_panel_reduction_aborts(lib, monkeypatch):
+    """Even uniform orders above 512 hand the last 512 columns of the panel-blocked reduction to the resident kernel
+    (csrc/eig_tridiag.hip, `hybrid`).  With that launch replaced by an aborted one, recover redoes phase 1 on the
+    panel launches alone; with NDMPS_TRD_NO_HYBRID the panel launches go to the end by themselves.  All three give
+    LAPACK's eigenpairs, the first two agree to rounding."""
+    n, k, batch = 1280, 96, 2
+    monkeypatch.setenv("NDMPS_TRD_PANEL_MIN", "513")
+    rng = np.random.default_rng(12)
+    g = np.stack([(lambda a: a.T @ a)(rng.standard_normal((n + 64, n)) * np.logspace(0, -5, n)[None, :]) for _ in range(batch)])
+    dg = torch.from_numpy(g).to(DEV)
+    v = torch.empty_like(dg)
+    w = torch.empty((batch, n), dtype=torch.float64, device=DEV)
+    nbytes = int(lib.ndmps_syevd_topk_workspace_bytes(n, batch, k))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    sizes = _lib.i64_array([n] * batch)
+    before = int(lib.ndmps_syevd_topk_team_fallbacks())
+    got = {}
+    for label, inject, expect, env in (("hybrid", 0, 0, None), ("aborted", 1, 1, None), ("panel", 1, 0, "NDMPS_TRD_NO_HYBRID")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        lib.ndmps_debug_inject_team_abort(inject)
+        _lib.check(lib.ndmps_syevd_topk_values_f64(batch, dg.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(), n,
+                                                   k, ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        rec = C.c_int(-1)
+        _lib.check(lib.ndmps_syevd_topk_recover_f64(batch, sizes, k, ws.data_ptr(), nbytes, C.byref(rec), _lib.stream_ptr()))
+        assert rec.value == expect, label
+        status = (C.c_int * batch)()
+        _lib.check(lib.ndmps_syevd_topk_vectors_f64(batch, sizes, _lib.i64_array([k] * batch), k, ws.data_ptr(), nbytes,
+                                                    status, _lib.stream_ptr()))
+        assert list(status) == [0] * batch, label
+        wv, vv = w.cpu().numpy().copy(), v.cpu().numpy().copy()
+        got[label] = (wv, vv)
+        for b in range(batch):
+            ref = np.linalg.eigvalsh(g[b])[::-1]
+            assert np.allclose(wv[b, :k], ref[:k], rtol=0, atol=1e-12 * ref[0]), label
+            vk = vv[b][:, :k]
+            assert np.abs(vk.T @ vk - np.eye(k)).max() < 1e-12, label
+            assert np.abs(g[b] @ vk - vk * wv[b, :k]).max() < 1e-11 * ref[0], label
+    lib.ndmps_debug_inject_team_abort(0)  # the panel-only pass has no resident launch to consume the injection
+    assert int(lib.ndmps_syevd_topk_team_fallbacks()) == before + 1
+    # the recovery IS the panel-only route: same kernels, same order, same bits
+    assert np.array_equal(got["aborted"][0][:, :k], got["panel"][0][:, :k])
+    assert np.array_equal(got["aborted"][1][:, :, :k], got["panel"][1][:, :, :k])
+    assert np.abs(got["hybrid"][0][:, :k] - got["panel"][0][:, :k]).max() <= 1e-13 * got["panel"][0].max()
+
+
 def test_an_unrecovered_abort_is_reported_not_hidden(lib):
     """Without the recover call the status stays 2 through phase 2 (a later Cholesky breakdown does not mask it)."""
     n, k = 256, 16
