@@ -407,18 +407,23 @@ __device__ __forceinline__ bool rec_ok(const team_u32x4& q, unsigned long long t
   v = __longlong_as_double((long long)(((unsigned long long)q[1] << 32) | q[0]));
   return (((unsigned long long)q[3] << 32) | q[2]) == tag;
 }
-// four records in flight, then one wait that names all four results (the compiler does not know these loads)
-__device__ __forceinline__ void rec_load4(const TeamRec* p0, const TeamRec* p1, const TeamRec* p2, const TeamRec* p3,
-                                          team_u32x4& q0, team_u32x4& q1, team_u32x4& q2, team_u32x4& q3) {
-#define NDMPS_REC_LOAD(q, p) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q) : "v"(p) : "memory")
-  NDMPS_REC_LOAD(q0, p0);
-  NDMPS_REC_LOAD(q1, p1);
-  NDMPS_REC_LOAD(q2, p2);
-  NDMPS_REC_LOAD(q3, p3);
-#undef NDMPS_REC_LOAD
+// every record of a poll in flight, then one wait that names all the results (the compiler does not know these loads)
+__device__ __forceinline__ void rec_issue(team_u32x4& q, const TeamRec* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void rec_wait4(team_u32x4& q0, team_u32x4& q1, team_u32x4& q2, team_u32x4& q3) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
 }
-
+template <int N>
+__device__ __forceinline__ void rec_wait(team_u32x4 (&q)[N]) {
+  static_assert(N == 4 || N == 8 || N == 16, "2, 4 or 8 rows per thread");
+  rec_wait4(q[0], q[1], q[2], q[3]);  // vmcnt(0): everything has landed; the further waits only name the registers
+  if constexpr (N >= 8) rec_wait4(q[4], q[5], q[6], q[7]);
+  if constexpr (N >= 16) {
+    rec_wait4(q[8], q[9], q[10], q[11]);
+    rec_wait4(q[12], q[13], q[14], q[15]);
+  }
+}
 __device__ __forceinline__ unsigned long long team_poll(const unsigned long long* p) {
   unsigned long long v;
   asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
@@ -459,13 +464,17 @@ __device__ __forceinline__ bool team_place(const TrdWork& w, int& member, int& t
 
 // CW: columns per workgroup, 32 (16 workgroups per order-512 matrix) or 8 (64 of them, for one to four matrices:
 // the tile loop is a quarter as long, the per-column arithmetic of the slowest member shrinks with it).
+// MR: the largest order an instantiation takes, 256 * NR rows (512: the matrices of the lockstep groups; 1024 and 2048,
+// with 8-column blocks and tagged records only: one or a few big matrices spread over the whole chip -- an order-2048
+// matrix is 128 registers per thread in 256 workgroups).  Dynamic LDS: MR row records.
 template <int NR, bool TAGGED, int CW = 32>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, NR <= 4 ? 2 : 1)
 trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
+  constexpr int MR = 256 * NR;
   constexpr int LPR = CW / 4;        // lanes per row, 4 columns (32 bytes) each
   constexpr int RPW = 64 / LPR;      // rows per wave instruction
   constexpr int RPI = 4 * RPW;       // rows per tile of the workgroup
-  constexpr int NT = 512 / RPI;      // tiles per lane: 512 rows
+  constexpr int NT = MR / RPI;       // tiles per lane: MR rows
   int member, team;
   if (!team_place(w, member, team)) return;
   TrdDesc& d = desc[b0 + team];
@@ -487,7 +496,8 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
   TeamRec* xr = w.xr + b * 2 * lda;
   const unsigned long long tag_base = (unsigned long long)epoch << 32;
   __shared__ double bc[4];  // y[j], y[j + 1], column[j + 1] of the tagged exchange, for every thread
-  __shared__ RowVec rv[512];
+  extern __shared__ double team_dyn[];
+  RowVec* rv = reinterpret_cast<RowVec*>(team_dyn);  // [MR]
   __shared__ double red_a[4], red_b[4];
   __shared__ double part[4][CW];
   __shared__ int go;
@@ -513,7 +523,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     a[u][3] = hi.y;
   }
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {  // rows beyond the order never change: zero operands
+  for (int r = 0; r < NR; ++r) {  // rows beyond the order never change: zero operands
     const int i = tid + 256 * r;
     if (i >= n) {
       RowVec z;
@@ -545,18 +555,26 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
       const double* yprev = ybuf + ((j - 1) & 1) * lda;
       const double* xcol = xc + (j & 1) * lda;
       if (TAGGED) {
-        static_assert(!TAGGED || NR == 2, "the tagged exchange loads two rows per thread");
         const TeamRec* yp = yr + ((j - 1) & 1) * lda;
         const TeamRec* xp = xr + (j & 1) * lda;
         const unsigned long long want = tag_base | (unsigned long long)j;
-        const int i0 = tid, i1 = tid + 256;
-        const bool in0 = i0 >= j && i0 < n, in1 = i1 >= j && i1 < n;
-        const int s0 = in0 ? i0 : j, s1 = in1 ? i1 : j;  // lanes without a row look at entry j (valid like any other)
         bool ok = false;
         for (unsigned polls = 1; !ok; ++polls) {
-          team_u32x4 q0, q1, q2, q3;
-          rec_load4(yp + s0, yp + s1, xp + s0, xp + s1, q0, q1, q2, q3);
-          ok = rec_ok(q0, want, yv[0]) & rec_ok(q1, want, yv[1]) & rec_ok(q2, want, rj[0]) & rec_ok(q3, want, rj[1]);
+          team_u32x4 qq[2 * NR];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int i = tid + 256 * r;
+            const int si = i >= j && i < n ? i : j;  // lanes without a row look at entry j (valid like any other)
+            rec_issue(qq[2 * r], yp + si);
+            rec_issue(qq[2 * r + 1], xp + si);
+          }
+          rec_wait(qq);
+          ok = true;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const bool oy = rec_ok(qq[2 * r], want, yv[r]), ox = rec_ok(qq[2 * r + 1], want, rj[r]);
+            ok = ok && oy && ox;
+          }
           if (!ok && (polls & 255u) == 0) {
             if (__hip_atomic_load(&sync->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                 wall_clock64() - t_start > kTeamSpinTicks) {
@@ -568,12 +586,13 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
         }
         // the three scalars every thread needs are entries j and j + 1: their holders pass them on through LDS
         // (read after the first barrier of the prologue)
-        if (i0 == j) { bc[0] = yv[0]; }
-        if (i1 == j) { bc[0] = yv[1]; }
-        if (i0 == j + 1) { bc[1] = yv[0]; bc[2] = rj[0]; }
-        if (i1 == j + 1) { bc[1] = yv[1]; bc[2] = rj[1]; }
-        if (!in0) yv[0] = rj[0] = 0.0;
-        if (!in1) yv[1] = rj[1] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int i = tid + 256 * r;
+          if (i == j) bc[0] = yv[r];
+          if (i == j + 1) { bc[1] = yv[r]; bc[2] = rj[r]; }
+          if (!(i >= j && i < n)) yv[r] = rj[r] = 0.0;
+        }
         v_j1 = rv[j + 1].vj;
       } else {
       y_j = team_load(yprev + j);
@@ -670,7 +689,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     double wc[4], vc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int cc = min(c + k, 511);  // records of columns >= n are zero
+      const int cc = min(c + k, MR - 1);  // records of columns >= n are zero
       wc[k] = rv[cc].wp;
       vc[k] = rv[cc].vp;
     }
@@ -2322,6 +2341,8 @@ int trd_opt_in() {
   if (dev < 0 || dev >= 64 || done[dev]) return NDMPS_OK;
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_tail_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLds));
+  NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_team_kernel<8, true, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * (int)sizeof(RowVec)));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_column_kernel<16, 32>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxN * (int)sizeof(RowVec)));
   NDMPS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trd_column_kernel<16, 8>),
@@ -2369,22 +2390,26 @@ int band_width_for(int64_t n_max) {
   return (bw == 2 || bw == 4) ? bw : 0;
 }
 
-// workgroups of trd_team_kernel the current device keeps resident at once (occupancy x compute units)
-int team_slots(int& slots) {
+// workgroups of trd_team_kernel the current device keeps resident at once (occupancy x compute units); rows_per_thread:
+// 2 (orders <= 512), 4 (<= 1024) or 8 (<= 2048: one workgroup per CU)
+int team_slots(int& slots, int rows_per_thread = 2) {
   static std::mutex mu;
-  static int cached[64] = {};
+  static int cached[3][64] = {};
   int dev = 0;
   NDMPS_CHECK_HIP(hipGetDevice(&dev));
   NDMPS_REQUIRE(dev >= 0 && dev < 64, "device index %d outside [0, 64)", dev);
+  const int cls = rows_per_thread <= 2 ? 0 : rows_per_thread <= 4 ? 1 : 2;
   std::lock_guard<std::mutex> lock(mu);
-  if (cached[dev] == 0) {
+  if (cached[cls][dev] == 0) {
     int per_cu = 0, cus = 0;
-    NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<2, true>, 256, 0));
+    if (cls == 0) NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<2, true>, 256, 512 * sizeof(RowVec)));
+    else if (cls == 1) NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<4, true, 8>, 256, 1024 * sizeof(RowVec)));
+    else NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<8, true, 8>, 256, 2048 * sizeof(RowVec)));
     NDMPS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // the register budget allows two 256-thread workgroups per CU; never count on more than that
-    cached[dev] = std::max(1, std::min(per_cu, 2)) * std::max(cus, 1);
+    // the register budget allows two 256-thread workgroups per CU (one of the 8-row kernel); never count on more
+    cached[cls][dev] = std::max(1, std::min(per_cu, cls == 2 ? 1 : 2)) * std::max(cus, 1);
   }
-  slots = cached[dev];
+  slots = cached[cls][dev];
   return NDMPS_OK;
 }
 
@@ -2529,7 +2554,36 @@ int pnl_run(const std::vector<PnlLaunch>& seq, int batch, const int64_t* h_n, in
 // Resident tridiagonalisation (trd_team_kernel and variants) of `batch` matrices of order <= 512 named by `desc`, all
 // columns up to the last kTail in one launch (or a few, by the resident slots); takes the device-side turn.  Used for
 // orders <= 512 and for the last 512 columns behind the panel-blocked reduction (a view of the workspace).
+std::atomic<unsigned> g_team_epoch{1};  // names a launch in the tags of its exchange records
 int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStream_t s) {
+    if (n_max > 512) {
+      // orders 513 .. 2048: 8-column blocks, 4 or 8 rows per thread, tagged records; 128 / 256 workgroups per matrix,
+      // so a team spans XCDs whatever the placement (the exchange is agent-scope: MALL, not an XCD's L2)
+      NDMPS_REQUIRE(n_max <= 2048, "resident reduction of order %lld > 2048", (long long)n_max);
+      const int nr = n_max <= 1024 ? 4 : 8;
+      int slots = 0;
+      NDMPS_TRY(team_slots(slots, nr));
+      const int team_size = (int)ndmps::ceil_div(n_max, 8);
+      const int per_launch = std::max(1, slots / team_size);
+      w.tail_lower = 0;
+      int inject = g_inject_abort.load();
+      while (inject > 0 && !g_inject_abort.compare_exchange_weak(inject, inject - 1)) {
+      }
+      if (inject > 0) {
+        hipLaunchKernelGGL(trd_inject_abort_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch);
+        return NDMPS_OK;
+      }
+      return team_launch(s, [&]() {
+        for (int b0 = 0; b0 < batch; b0 += per_launch) {
+          const unsigned epoch = g_team_epoch.fetch_add(1);
+          const dim3 grid((unsigned)team_size, (unsigned)std::min(per_launch, batch - b0));
+          TrdWork wl = w;
+          wl.xcd_count = 0;
+          if (nr == 4) hipLaunchKernelGGL((trd_team_kernel<4, true, 8>), grid, dim3(256), 1024 * sizeof(RowVec), s, desc, wl, b0, epoch);
+          else hipLaunchKernelGGL((trd_team_kernel<8, true, 8>), grid, dim3(256), 2048 * sizeof(RowVec), s, desc, wl, b0, epoch);
+        }
+      });
+    }
     // a launch never holds more workgroups than the device keeps resident at once: no team then depends on the
     // order in which the dispatcher places workgroups (larger batches go in several launches)
     int slots = 0;
@@ -2554,7 +2608,6 @@ int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStre
       hipLaunchKernelGGL(trd_inject_abort_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch);
     } else
     NDMPS_TRY(team_launch(s, [&]() {
-      static std::atomic<unsigned> epoch_counter{1};
       // exchange without meetings (tagged records) while every workgroup has a CU's SIMDs to itself: 3-4 % faster
       // for up to 16 order-512 matrices; with two workgroups per CU the polls of the waiting one get in the way of
       // the working one and the counter is as fast (2.49 vs 2.53 ms for 32 matrices).  Environment: A/B.
@@ -2562,7 +2615,7 @@ int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStre
                           : getenv("NDMPS_TRD_TEAM_TAGGED") ? true
                                                             : (int64_t)std::min(per_launch, batch) * team_size <= slots / 2;
       for (int b0 = 0; b0 < batch; b0 += per_launch) {
-        const unsigned epoch = epoch_counter.fetch_add(1);
+        const unsigned epoch = g_team_epoch.fetch_add(1);
         const int count = std::min(per_launch, batch - b0);
         TrdWork wl = w;
         dim3 grid((unsigned)team_size, (unsigned)count);
@@ -2575,9 +2628,9 @@ int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStre
           grid = dim3((unsigned)(team_size * count));
         }
         if (sym) hipLaunchKernelGGL(trd_sym_kernel, grid, dim3(256), 0, s, desc, wl, b0);
-        else if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
-        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
-        else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 0, s, desc, wl, b0, epoch);
+        else if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 512 * sizeof(RowVec), s, desc, wl, b0, epoch);
+        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 512 * sizeof(RowVec), s, desc, wl, b0, epoch);
+        else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 512 * sizeof(RowVec), s, desc, wl, b0, epoch);
       }
     }, (int64_t)std::min(per_launch, batch) * team_size <= slots / 2));  // half a turn only for what fits half the slots
   return NDMPS_OK;
@@ -2645,32 +2698,47 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
     NDMPS_LAUNCH_CHECK();
     return NDMPS_OK;
   }
-  // Hand-over of a panel-blocked reduction to the resident kernel for its last 512 columns: a column costs that kernel
-  // ~4 us (one exchange inside a team of workgroups) against ~11 us of the two launches.  Needs one order for the whole
-  // batch (the view below is one offset into the workspace), an even one (the parity of a column selects its exchange
-  // buffer on both sides), the resident launches switched on, and every team of the batch resident in one launch.
-  constexpr int kHybrid = 512;
-  bool hybrid = !team && n_max - kHybrid >= kPnlTB && n_max % 2 == 0 && !g_team_off && !getenv("NDMPS_TRD_NO_TEAM") &&
-                !getenv("NDMPS_TRD_NO_HYBRID");
-  for (int b = 0; b < batch && hybrid; ++b) hybrid = h_n[b] == n_max;
-  if (hybrid) {
+  // Orders 513 .. 2048 whose teams (n / 8 workgroups each) are all resident at once: the whole reduction in the
+  // resident kernel (3 - 5 us per column against 11 us of the two panel launches).  NDMPS_TRD_TEAM_MAX=512 keeps it
+  // to the orders of the lockstep groups (A/B timing, tests of the other routes).
+  const bool team_on = !bw && !g_team_off && !getenv("NDMPS_TRD_NO_TEAM");
+  const int64_t team_max = getenv("NDMPS_TRD_TEAM_MAX") ? std::max<int64_t>(atoll(getenv("NDMPS_TRD_TEAM_MAX")), 512) : 2048;
+  auto team_fits = [&](int64_t order, bool& fits) -> int {
     int slots = 0;
-    NDMPS_TRY(team_slots(slots));
-    hybrid = (int64_t)batch * (kHybrid / 8) <= slots;
+    NDMPS_TRY(team_slots(slots, order <= 512 ? 2 : order <= 1024 ? 4 : 8));
+    fits = (int64_t)batch * ndmps::ceil_div(order, 8) <= slots;
+    return NDMPS_OK;
+  };
+  bool big_team = false;
+  if (team_on && n_max > 512 && n_max <= std::min<int64_t>(team_max, 2048)) NDMPS_TRY(team_fits(n_max, big_team));
+  // Hand-over of a panel-blocked reduction to the resident kernel for its last 2048 / 1024 / 512 columns.  Needs one
+  // order for the whole batch (the view below is one offset into the workspace), an even one (the parity of a column
+  // selects its exchange buffer on both sides), the resident launches switched on, and every team of the batch
+  // resident in one launch.
+  int hybrid = 0;
+  if (team_on && !big_team && n_max > 512 && n_max % 2 == 0 && !getenv("NDMPS_TRD_NO_HYBRID")) {
+    bool uniform = true;
+    for (int b = 0; b < batch && uniform; ++b) uniform = h_n[b] == n_max;
+    for (int h = 2048; h >= 512 && uniform && !hybrid; h /= 2) {
+      bool fits = false;
+      if (h > team_max || n_max - h < kPnlTB) continue;
+      NDMPS_TRY(team_fits(h, fits));
+      if (fits) hybrid = h;
+    }
   }
   void* span = ndmps::span_begin(s);
   int64_t span_bytes = 0;  // algorithmic: every trailing element read once and written once per column
-  if (team) {
+  if (team || big_team) {
     NDMPS_TRY(trd_team_reduce(batch, n_max, desc, w, s));
     // algorithmic traffic of the resident reduction: the matrix in, the reflectors out
     for (int b = 0; b < batch; ++b) span_bytes += 2 * 8 * h_n[b] * h_n[b];
     ndmps::span_end(span, s, ndmps::kSpanTridiagTeam, 1, span_bytes);
-  } else if (n_max >= panel_min_order(hybrid) && !getenv("NDMPS_TRD_NO_PANEL")) {
+  } else if (n_max >= panel_min_order(hybrid != 0) && !getenv("NDMPS_TRD_NO_PANEL")) {
     // panel-blocked reduction (eig_panel.inc): two launches per column, one update per panel of kPnlNB columns
     NDMPS_CHECK_HIP(hipMemsetAsync(w.Vh, 0, (size_t)batch * n_max * l.lda * 8, s));
     NDMPS_CHECK_HIP(hipMemsetAsync(w.pv, 0, (size_t)batch * n_max * kPnlNB * 8, s));
     NDMPS_CHECK_HIP(hipMemsetAsync(w.pw, 0, (size_t)batch * n_max * kPnlNB * 8, s));
-    const int tail_cols = hybrid ? kHybrid : kTail;
+    const int tail_cols = hybrid ? hybrid : kTail;
     w.tail_lower = hybrid ? 0 : 1;
     const int J_max = (int)n_max - tail_cols;
     std::vector<char> ends((size_t)J_max + 1, 0);
@@ -2696,10 +2764,10 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
       // the trailing 512 x 512 block in full storage, then the resident kernel on a VIEW of the workspace: matrix,
       // reflector rows, T's diagonals and the pending product of its last column all sit at offset J0 of the big
       // arrays, so the tail kernel finds everything where the column launches would have left it
-      const int64_t J0 = n_max - kHybrid;
+      const int64_t J0 = n_max - hybrid;
       TrdDesc* sub = (TrdDesc*)((char*)w_in.A - l.off_a + l.off_desc2);
-      hipLaunchKernelGGL(pnl_mirror_kernel, dim3(256, B), dim3(256), 0, s, w, (int)n_max, kHybrid);
-      hipLaunchKernelGGL(pnl_subdesc_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, (const TrdDesc*)desc, sub, batch, kHybrid);
+      hipLaunchKernelGGL(pnl_mirror_kernel, dim3(256, B), dim3(256), 0, s, w, (int)n_max, hybrid);
+      hipLaunchKernelGGL(pnl_subdesc_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, (const TrdDesc*)desc, sub, batch, hybrid);
       TrdWork v = w;
       v.A = w.A + J0 * l.lda + J0;
       v.Vh = w.Vh + J0 * l.lda + J0;
@@ -2707,7 +2775,7 @@ int trd_reduce_and_values(int batch, const int64_t* h_n, int64_t n_max, int64_t 
       v.tau = w.tau + J0;
       v.d = w.d + J0;
       v.e = w.e + J0;
-      NDMPS_TRY(trd_team_reduce(batch, kHybrid, sub, v, s));
+      NDMPS_TRY(trd_team_reduce(batch, hybrid, sub, v, s));
       hipLaunchKernelGGL(pnl_substatus_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, (const TrdDesc*)sub, batch);
       w.tail_lower = 0;  // the resident kernel hands the trailing block over in full storage
     } else {

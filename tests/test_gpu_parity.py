@@ -780,13 +780,18 @@ def test_topk_solver_orders_above_512_in_mixed_batches():
             _check_topk(g, w, v, k, k_max=128)
 
 
-@pytest.mark.parametrize("n", [640, 1537, 3000, 4096])
-def test_topk_solver_panel_blocked_reduction(n, monkeypatch):
-    """Orders from 1536 on (here: from 513 on, NDMPS_TRD_PANEL_MIN) are reduced panel by panel (csrc/eig_panel.inc: two launches per column on the lower tiles, one
-    MFMA update per 32 columns): orders that are no multiple of the 64-wide tiles or of the panel width, the largest
+@pytest.mark.parametrize("n,team_max", [(640, 512), (1537, 512), (3000, 512), (4096, 512), (2500, 1024), (3000, None),
+                                        (4096, None)])
+def test_topk_solver_panel_blocked_reduction(n, team_max, monkeypatch):
+    """Orders the resident kernel does not take whole (above 2048; here, with NDMPS_TRD_TEAM_MAX=512, above 512) are
+    reduced panel by panel (csrc/eig_panel.inc: two launches per column on the lower tiles, one MFMA update per 32
+    columns) and, when the order is even, handed to the resident kernel for the last 2048 / 1024 / 512 columns: orders
+    that are no multiple of the 64-wide tiles or of the panel width, odd ones (panel launches to the end), the largest
     order the solver takes, 128 vectors."""
     lib = _lib.load()
     monkeypatch.setenv("NDMPS_TRD_PANEL_MIN", "513")
+    if team_max:
+        monkeypatch.setenv("NDMPS_TRD_TEAM_MAX", str(team_max))
     rng = np.random.default_rng(n)
     a = rng.standard_normal((n + 5, n)) * np.logspace(0, -5, n)[None, :]
     g = a.T @ a
@@ -794,12 +799,15 @@ def test_topk_solver_panel_blocked_reduction(n, monkeypatch):
     _check_topk(g, w, v, 128)
 
 
-def test_topk_solver_panel_blocked_reduction_degenerate_spectra(monkeypatch):
-    """The panel path on matrices whose reflectors vanish or whose spectra are multiple: zero, identity, rank one,
-    exact multiplicities, diagonal, decoupled identical blocks, orders 600 .. 700 in ONE batch (mixed orders: the
-    kernels read the order from the descriptors)."""
+@pytest.mark.parametrize("route", ["panel", "resident"])
+def test_topk_solver_panel_blocked_reduction_degenerate_spectra(route, monkeypatch):
+    """The panel path, and the resident kernel at orders above 512, on matrices whose reflectors vanish or whose
+    spectra are multiple: zero, identity, rank one, exact multiplicities, diagonal, decoupled identical blocks, orders
+    600 .. 700 in ONE batch (mixed orders: the kernels read the order from the descriptors)."""
     lib = _lib.load()
     monkeypatch.setenv("NDMPS_TRD_PANEL_MIN", "513")
+    if route == "panel":
+        monkeypatch.setenv("NDMPS_TRD_TEAM_MAX", "512")
     rng = np.random.default_rng(2)
     n = 600
     u = rng.standard_normal(n)
@@ -809,8 +817,13 @@ def test_topk_solver_panel_blocked_reduction_degenerate_spectra(monkeypatch):
     cases = [(np.zeros((n, n)), 8), (np.eye(n), 8), (np.outer(u, u), 8), ((q * lam) @ q.T, 30),
              (np.diag(np.arange(n, 0, -1.0)), 10), (np.kron(np.eye(10), blk @ blk.T), 40), (np.eye(650) * 3.0, 50)]
     mats = [0.5 * (g + g.T) for g, _ in cases]
-    for g, k, (w, v) in zip(mats, [k for _, k in cases], _topk(lib, mats, [k for _, k in cases])):
-        _check_topk(g, w, v, k, tol_scale=4.0, k_max=50)
+    ks = [k for _, k in cases]
+    # the resident route needs every team of a batch resident at once: 82 workgroups per matrix here, three at a time
+    step = len(mats) if route == "panel" else 3
+    for at in range(0, len(mats), step):
+        part, kpart = mats[at:at + step], ks[at:at + step]
+        for g, k, (w, v) in zip(part, kpart, _topk(lib, part, kpart, k_max=50)):
+            _check_topk(g, w, v, k, tol_scale=4.0, k_max=50)
 
 
 def test_topk_solver_panel_path_against_the_column_launches(monkeypatch):
@@ -819,6 +832,7 @@ def test_topk_solver_panel_path_against_the_column_launches(monkeypatch):
     reduction it replaces from order 1536 on (same eigenvalues, same kept subspace)."""
     lib = _lib.load()
     monkeypatch.setenv("NDMPS_TRD_PANEL_MIN", "513")
+    monkeypatch.setenv("NDMPS_TRD_TEAM_MAX", "512")
     rng = np.random.default_rng(3)
     mats = []
     for n in (1100, 777):

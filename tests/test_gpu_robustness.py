@@ -45,10 +45,12 @@ def _spd(n, seed):
     return a.T @ a
 
 
-def test_solver_recovers_from_an_aborted_resident_launch(lib):
+@pytest.mark.parametrize("n,batch", [(256, 3), (900, 2), (1600, 1)])
+def test_solver_recovers_from_an_aborted_resident_launch(lib, n, batch):
     """values -> recover -> vectors: with status 2 injected, recover redoes phase 1 on the column launches, says so,
-    and the eigenpairs are LAPACK's."""
-    n, k, batch = 256, 32, 3
+    and the eigenpairs are LAPACK's.  Orders up to 2048 take the resident launch whole (4 and 8 rows per thread above
+    512) when their teams fit the chip together."""
+    k = 32
     g = np.stack([_spd(n, 10 + b) for b in range(batch)])
     dg = torch.from_numpy(g).to(DEV)
     v = torch.empty_like(dg)

@@ -1,22 +1,39 @@
-"""Phase clocks of trd_team_kernel's last workgroup (build with make EXTRA=-DNDMPS_TEAM_STAMPS): cycles per column."""
-import os, sys
-import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from imgcompressionmps_amd import _lib
+"""Where a column of the resident reduction goes (scratch): needs tools/scratch/stamps/libndmps_stamps.so, the library
+with eig_tridiag.hip compiled -DNDMPS_TEAM_STAMPS (accumulated shader-clock cycles per phase in the last workgroup).
+usage: python tools/scratch/team_stamps.py [orders]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from imgcompressionmps_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "scratch", "stamps", "libndmps_stamps.so")
 lib = _lib.load()
-B, n, k = int(sys.argv[1]), 512, 64
-rng = np.random.default_rng(1)
-g = np.stack([(lambda x: x.T @ x)(rng.standard_normal((2 * n, n))) for _ in range(B)])
-g0 = torch.from_numpy(g).cuda()
-v = torch.empty_like(g0); w = torch.empty((B, n), dtype=torch.float64, device="cuda")
-nb = lib.ndmps_syevd_topk_workspace_bytes(n, B, k)
-ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-sizes = _lib.i64_array([n] * B)
-for _ in range(3):
-    _lib.check(lib.ndmps_syevd_topk_values_f64(B, g0.data_ptr(), n * n, sizes, v.data_ptr(), n * n, w.data_ptr(), n, k, ws.data_ptr(), nb, _lib.stream_ptr()))
-torch.cuda.synchronize()
-off = lib.ndmps_syevd_topk_stamps_offset(n, B, k)
-names = ["loads of y, column", "dot: sum, barrier", "sigma: sum, barrier", "householder, records, barrier", "tile loop", "fold, barrier, publish y", "publish column, ack, meeting"]
-for b in (0, B - 1):
-    st = np.frombuffer(ws[off + b * 128: off + b * 128 + 56].cpu().numpy().tobytes(), dtype=np.int64)
-    print(f"matrix {b}: cycles per column:", ", ".join(f"{nm} {c / 384:.0f}" for nm, c in zip(names, st)), "| total", round(st.sum() / 384))
+dev = "cuda:0"
+names = ["poll", "barrier1", "sigma", "records", "body", "sums", "meeting", "-"]
+for n in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "512,1024,2048").split(",")]:
+    gen = torch.Generator(device=dev).manual_seed(n)
+    a = torch.randn((n + 64, n), dtype=torch.float64, device=dev, generator=gen)
+    g = (a.T @ a).contiguous()
+    k = 64
+    nb = lib.ndmps_syevd_topk_workspace_bytes(n, 1, k)
+    ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    v = torch.zeros_like(g)
+    w = torch.zeros(n, dtype=torch.float64, device=dev)
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.ndmps_syevd_topk_values_f64(1, g.data_ptr(), n * n, _lib.i64_array([n]), v.data_ptr(), n * n, w.data_ptr(), n, k,
+                                                   ws.data_ptr(), nb, _lib.stream_ptr()))
+        e1.record()
+        torch.cuda.synchronize()
+    off = lib.ndmps_syevd_topk_stamps_offset(n, 1, k)
+    st = ws[off:off + 64].view(torch.int64).cpu().numpy().astype(np.float64)
+    cols = n - 128
+    tot = st.sum()
+    print(f"n={n}: values {e0.elapsed_time(e1):.3f} ms; cycles per column {tot / cols:.0f}: " +
+          ", ".join(f"{nm} {c / cols:.0f}" for nm, c in zip(names, st) if nm != "-"), flush=True)
