@@ -411,6 +411,16 @@ __device__ __forceinline__ bool rec_ok(const team_u32x4& q, unsigned long long t
 __device__ __forceinline__ void rec_issue(team_u32x4& q, const TeamRec* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(q) : "v"(p) : "memory");
 }
+// the same with a wave-uniform base (scalar registers) and a 32-bit byte offset per lane; IMM: 0 or 16 bytes on top
+template <int IMM>
+__device__ __forceinline__ void rec_issue_s(team_u32x4& q, unsigned off, const TeamRec* base) {
+  static_assert(IMM == 0 || IMM == 16, "entry 0 or 1 behind the base");
+  if constexpr (IMM == 0) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(q) : "v"(off), "s"(base) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:16 sc1" : "=v"(q) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void rec_wait3(team_u32x4& q0, team_u32x4& q1, team_u32x4& q2) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2) : : "memory");
+}
 __device__ __forceinline__ void rec_wait4(team_u32x4& q0, team_u32x4& q1, team_u32x4& q2, team_u32x4& q3) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
 }
@@ -495,8 +505,7 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
   TeamRec* yr = w.yr + b * 2 * lda;
   TeamRec* xr = w.xr + b * 2 * lda;
   const unsigned long long tag_base = (unsigned long long)epoch << 32;
-  __shared__ double bc[4];  // y[j], y[j + 1], column[j + 1] of the tagged exchange, for every thread
-  extern __shared__ double team_dyn[];
+  extern __shared__ __attribute__((aligned(32))) double team_dyn[];  // 32: row records are read and written as two b128
   RowVec* rv = reinterpret_cast<RowVec*>(team_dyn);  // [MR]
   __shared__ double red_a[4], red_b[4];
   __shared__ double part[4][CW];
@@ -534,6 +543,9 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
   double vv[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) vv[r] = 0.0;
+  // byte offset of a lane's row in the record arrays, -16 for rows beyond the order (recomputed where it is used: the
+  // 32-column blocks have no register to keep it in)
+  auto row_off_of = [&](int r) { return tid + 256 * r < n ? 16 * (tid + 256 * r) : -16; };
   double taup = 0.0;
   unsigned long long target = 0;
   int failed = 0;
@@ -558,40 +570,73 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
         const TeamRec* yp = yr + ((j - 1) & 1) * lda;
         const TeamRec* xp = xr + (j & 1) * lda;
         const unsigned long long want = tag_base | (unsigned long long)j;
-        bool ok = false;
+        // a lane's rows at and below j (rows above it and rows beyond the order look at entry j, valid like any other):
+        // one max per row on the byte offsets; the bases are wave-uniform
+        int row_off[NR];
+        unsigned off[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          row_off[r] = row_off_of(r);
+          off[r] = (unsigned)max(row_off[r], 16 * j);
+        }
+        auto give_up = [&](unsigned polls) -> bool {  // every 256th unsuccessful poll: the abort flag and the clock
+          if ((polls & 255u) != 0) return false;
+          if (__hip_atomic_load(&sync->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+              wall_clock64() - t_start > kTeamSpinTicks) {
+            __hip_atomic_store(&sync->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            failed = 1;
+            return true;
+          }
+          return false;
+        };
+        // the three scalars every thread needs are entries j and j + 1: one address for the whole wave each.  Teams of
+        // 128 / 256 workgroups wait on THESE first (192 bytes per wave and poll) and fetch their rows once they carry
+        // the column's tag: a poll of all rows is 4 - 17 MB across the chip, and the rows of a column are published
+        // within a fraction of a microsecond of each other.  A team inside one XCD polls everything at once (one round
+        // trip less; its polls stay in that XCD's L2).
+        constexpr bool kScalarsFirst = NR >= 4;
+        static_assert(!TAGGED || CW == 8, "32-column blocks (128 registers of matrix per thread) have no room for the records in flight");
+        bool ok = !kScalarsFirst;
         for (unsigned polls = 1; !ok; ++polls) {
-          team_u32x4 qq[2 * NR];
+          team_u32x4 qj, qj1, qx1;
+          rec_issue_s<0>(qj, 0u, yp + j);
+          rec_issue_s<16>(qj1, 0u, yp + j);
+          rec_issue_s<16>(qx1, 0u, xp + j);
+          rec_wait3(qj, qj1, qx1);
+          const bool o0 = rec_ok(qj, want, y_j), o1 = rec_ok(qj1, want, y_j1), o2 = rec_ok(qx1, want, r_j1);
+          ok = o0 && o1 && o2;
+          if (!ok && give_up(polls)) break;
+        }
+        ok = false;
+        for (unsigned polls = 1; !ok && !failed; ++polls) {
+          team_u32x4 qq[2 * NR], qj, qj1, qx1;
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            const int i = tid + 256 * r;
-            const int si = i >= j && i < n ? i : j;  // lanes without a row look at entry j (valid like any other)
-            rec_issue(qq[2 * r], yp + si);
-            rec_issue(qq[2 * r + 1], xp + si);
+            rec_issue_s<0>(qq[2 * r], off[r], yp);
+            rec_issue_s<0>(qq[2 * r + 1], off[r], xp);
+          }
+          if (!kScalarsFirst) {
+            rec_issue_s<0>(qj, 0u, yp + j);
+            rec_issue_s<16>(qj1, 0u, yp + j);
+            rec_issue_s<16>(qx1, 0u, xp + j);
           }
           rec_wait(qq);
           ok = true;
+          if (!kScalarsFirst) {
+            rec_wait3(qj, qj1, qx1);
+            const bool o0 = rec_ok(qj, want, y_j), o1 = rec_ok(qj1, want, y_j1), o2 = rec_ok(qx1, want, r_j1);
+            ok = o0 && o1 && o2;
+          }
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
             const bool oy = rec_ok(qq[2 * r], want, yv[r]), ox = rec_ok(qq[2 * r + 1], want, rj[r]);
             ok = ok && oy && ox;
           }
-          if (!ok && (polls & 255u) == 0) {
-            if (__hip_atomic_load(&sync->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                wall_clock64() - t_start > kTeamSpinTicks) {
-              __hip_atomic_store(&sync->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              failed = 1;
-              break;
-            }
-          }
+          if (!ok && give_up(polls)) break;
         }
-        // the three scalars every thread needs are entries j and j + 1: their holders pass them on through LDS
-        // (read after the first barrier of the prologue)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          const int i = tid + 256 * r;
-          if (i == j) bc[0] = yv[r];
-          if (i == j + 1) { bc[1] = yv[r]; bc[2] = rj[r]; }
-          if (!(i >= j && i < n)) yv[r] = rj[r] = 0.0;
+          if (row_off[r] < 16 * j) yv[r] = rj[r] = 0.0;  // finished rows, rows beyond the order (-16)
         }
         v_j1 = rv[j + 1].vj;
       } else {
@@ -627,11 +672,6 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
       if (__syncthreads_or(failed)) {  // a wait ran out of time somewhere in the team: everybody leaves
         if (tid == 0) d.status = 2;
         return;
-      }
-      if (j >= 1) {
-        y_j = bc[0];
-        y_j1 = bc[1];
-        r_j1 = bc[2];
       }
     } else {
       __syncthreads();
@@ -671,14 +711,18 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
         rec.pad = 0.0;
         rv[i] = rec;
         vv[r] = v;
-        if (writer) Vh[(int64_t)j * lda + i] = v;
-        if (writer && i == j) {
+      }
+    }
+    if (writer) {  // uniform: one workgroup of the team per column
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int i = tid + 256 * r;
+        if (i < lda) Vh[(int64_t)j * lda + i] = vv[r];  // zeros beyond the order
+        if (i == j) {
           w.d[b * w.n_max + j] = rj[r];
           w.e[b * w.n_max + j] = beta;
           w.tau[b * w.n_max + j] = tau;
         }
-      } else if (writer && i < lda) {
-        Vh[(int64_t)j * lda + i] = 0.0;
       }
     }
     taup = tau;
@@ -729,7 +773,8 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
     }
     TEAM_STAMP(5)
     if (j + 1 >= J) break;  // the tail kernel continues from the stored matrix
-    // ---- column j + 1 of the updated matrix, by its owner
+    // ---- column j + 1 of the updated matrix, by its owner (publishing it before the column sums are folded gains
+    //      nothing at orders <= 1024 and costs the 32-column kernel its last registers)
     if (member == (j + 1) / CW) {
       const int kk = j + 1 - c0;
       if (p == kk / 4) {
@@ -2402,7 +2447,7 @@ int team_slots(int& slots, int rows_per_thread = 2) {
   std::lock_guard<std::mutex> lock(mu);
   if (cached[cls][dev] == 0) {
     int per_cu = 0, cus = 0;
-    if (cls == 0) NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<2, true>, 256, 512 * sizeof(RowVec)));
+    if (cls == 0) NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<2, false>, 256, 512 * sizeof(RowVec)));
     else if (cls == 1) NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<4, true, 8>, 256, 1024 * sizeof(RowVec)));
     else NDMPS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trd_team_kernel<8, true, 8>, 256, 2048 * sizeof(RowVec)));
     NDMPS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -2608,12 +2653,9 @@ int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStre
       hipLaunchKernelGGL(trd_inject_abort_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch);
     } else
     NDMPS_TRY(team_launch(s, [&]() {
-      // exchange without meetings (tagged records) while every workgroup has a CU's SIMDs to itself: 3-4 % faster
-      // for up to 16 order-512 matrices; with two workgroups per CU the polls of the waiting one get in the way of
-      // the working one and the counter is as fast (2.49 vs 2.53 ms for 32 matrices).  Environment: A/B.
-      const bool tagged = getenv("NDMPS_TRD_TEAM_COUNTER") ? false
-                          : getenv("NDMPS_TRD_TEAM_TAGGED") ? true
-                                                            : (int64_t)std::min(per_launch, batch) * team_size <= slots / 2;
+      // 8-column blocks exchange without meetings (tagged records), 32-column blocks meet at a counter: a tagged
+      // 32-column kernel was 3 % faster for 9 .. 16 order-512 matrices (1.84 vs 1.90 ms) and as fast for 32, but its 128
+      // registers of matrix per thread leave no room for the records in flight (round 4: spills, removed)
       for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const unsigned epoch = g_team_epoch.fetch_add(1);
         const int count = std::min(per_launch, batch - b0);
@@ -2629,7 +2671,6 @@ int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStre
         }
         if (sym) hipLaunchKernelGGL(trd_sym_kernel, grid, dim3(256), 0, s, desc, wl, b0);
         else if (narrow_team) hipLaunchKernelGGL((trd_team_kernel<2, true, 8>), grid, dim3(256), 512 * sizeof(RowVec), s, desc, wl, b0, epoch);
-        else if (tagged) hipLaunchKernelGGL((trd_team_kernel<2, true>), grid, dim3(256), 512 * sizeof(RowVec), s, desc, wl, b0, epoch);
         else hipLaunchKernelGGL((trd_team_kernel<2, false>), grid, dim3(256), 512 * sizeof(RowVec), s, desc, wl, b0, epoch);
       }
     }, (int64_t)std::min(per_launch, batch) * team_size <= slots / 2));  // half a turn only for what fits half the slots
@@ -3086,6 +3127,11 @@ extern "C" int ndmps_syevd_topk_set_team(int enabled) {
 }
 // number of times a resident launch was given up and its work redone on the column launches (whole process)
 extern "C" int64_t ndmps_syevd_topk_team_fallbacks(void) { return g_team_fallbacks.load(); }
+extern "C" int ndmps_syevd_topk_team_slots(int64_t order) {
+  int slots = 0;
+  if (trd_opt_in() != NDMPS_OK || team_slots(slots, order <= 512 ? 2 : order <= 1024 ? 4 : 8) != NDMPS_OK) return 0;
+  return slots;
+}
 extern "C" int ndmps_syevd_topk_note_team_fallback(void) {  // for callers that redo their own sequence
   g_team_fallbacks.fetch_add(1);
   return NDMPS_OK;

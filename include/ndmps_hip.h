@@ -270,11 +270,15 @@ int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const int64_t* h
  * thread, returns the previous setting.  _team_fallbacks: how often a resident launch was given up and redone
  * (process-wide); _note_team_fallback: for callers that repeat a sequence of their own.
  * ndmps_debug_inject_team_abort(n): TEST HOOK -- the next n resident launches are replaced by what an aborted one
- * leaves behind (status 2, reduction not done), without the 3 s wait. */
+ * leaves behind (status 2, reduction not done), without the 3 s wait.
+ * _team_slots(order): workgroups of the resident kernel that takes matrices of `order` (<= 512, <= 1024, <= 2048) the
+ * current device keeps resident at once (occupancy x compute units); a batch whose teams -- order / 8 workgroups per
+ * matrix -- exceed it takes another route (more launches, the panel-blocked reduction); 0 on error. */
 int ndmps_syevd_topk_recover_f64(int batch, const int64_t* h_n, int64_t k_max, void* d_ws, int64_t ws_bytes,
                                  int* h_recovered, ndmps_stream_t stream);
 int ndmps_syevd_topk_set_team(int enabled);
 int64_t ndmps_syevd_topk_team_fallbacks(void);
+int ndmps_syevd_topk_team_slots(int64_t order);
 int ndmps_syevd_topk_note_team_fallback(void);
 int ndmps_debug_inject_team_abort(int launches);
 /* TEST HOOK: the cross-lane sums the tridiagonalisation kernels fold with (csrc/lanes.h: DPP moves and permlane swaps in

@@ -16,6 +16,8 @@ from oracle.metrics import synthetic_mri  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+if os.environ.get("NDMPS_PROBE_LIB"):  # A/B against another build of the library
+    _lib.LIB_PATH = os.environ["NDMPS_PROBE_LIB"]
 lib = _lib.load()
 dev = "cuda:0"
 vols = [torch.from_numpy(synthetic_mri((128, 128, 128), seed=s)).to(dev) for s in range(min(B, 4))]
