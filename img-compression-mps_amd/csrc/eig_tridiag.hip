@@ -2247,13 +2247,15 @@ __global__ void trd_inject_abort_kernel(TrdDesc* __restrict__ desc, int batch) {
 // ------------------------------------------------------------------------------------------ host side
 constexpr bool kTeamXcdDefault = true;   // teams placed XCD by XCD (team_place) when NDMPS_TRD_XCD is not set
 constexpr bool kSymDefault = false;  // half-storage team kernel (batches beyond half the workgroup slots) when NDMPS_TRD_SYM is not set
+constexpr int kWideOrthoMinOrder = 1024;  // chip-wide orthonormalisation of <= 128 vectors: from this order on ...
+constexpr int kWideOrthoMaxBatch = 2;      // ... for at most this many matrices (they go one after the other)
 constexpr int kBandDefault = 0;  // semi-bandwidth of the two-stage reduction when NDMPS_TRD_BAND is not set (0: off)
 
 struct TrdLayout {
   int64_t n_max, lda, kp;
   int64_t off_a, off_vh, off_y, off_xc, off_yr, off_xr, off_sync, off_tau, off_d, off_e, off_lam, off_mu, off_bound, off_z, off_lu, off_piv, off_desc, off_desc2, off_stamps, off_tw, t_stride, off_yb, off_xb, off_band, off_qlog, q_stride, off_yrow, total;
   int64_t off_pv, off_pw, off_ypart, off_spart, off_ucol, off_napart, pnl_blocks, pnl_tiles;
-  int64_t off_ws, off_wlinv, off_wgram, off_wt, wt_stride, kw, wgram_bytes;  // more than kMaxK vectors (eig_wide.inc)
+  int64_t off_ws, off_wlinv, off_wgram, off_wt, wt_stride, kw, wgram_bytes, off_wpart, wpart_stride;  // more than kMaxK vectors (eig_wide.inc)
 };
 
 TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
@@ -2311,13 +2313,19 @@ TrdLayout trd_layout(int64_t n_max, int64_t batch, int64_t k_max) {
   l.off_napart = take(panel_ok ? batch * 2 * l.pnl_blocks * kPnlNa * 8 : 0);
   // more than kMaxK eigenvectors (eig_wide.inc): Gram matrix, L^-1 and the Gram kernel's partial tiles, one set for
   // the whole batch (its matrices are orthonormalised one after the other)
-  l.kw = k_max > kMaxK ? ndmps::round_up(k_max, kWB) : 0;
-  l.wgram_bytes = l.kw ? ndmps_gram_f64_workspace_bytes(n_max, k_max) : 0;
+  // ... and one or two big matrices with up to kMaxK vectors: the single workgroup per matrix of trd_ortho_*_kernel
+  // takes 1.2 ms for 128 vectors of order 2048, the chip 0.2 ms
+  const bool wide_small = n_max >= kWideOrthoMinOrder && batch <= kWideOrthoMaxBatch;
+  l.kw = (k_max > kMaxK || wide_small) ? ndmps::round_up(l.kp, kWB) : 0;
+  l.wgram_bytes = l.kw ? ndmps_gram_f64_workspace_bytes(n_max, l.kp) : 0;
   l.off_ws = take(l.kw * l.kw * 8);
   l.off_wlinv = take(l.kw * l.kw * 8);
   l.off_wgram = take(l.wgram_bytes);
   l.wt_stride = l.kw ? ndmps::ceil_div(n_max, kBwB) * kBwB * kBwB : 0;  // T factors of the blocked back-transformation
   l.off_wt = take(batch * l.wt_stride * 8);
+  // partial products of the row-dealt back-transformation (back_rows_step_kernel): [2][chunks][64][kp] per matrix
+  l.wpart_stride = wide_small ? 2 * ndmps::ceil_div(n_max, kBrR) * kBwB * l.kp : 0;
+  l.off_wpart = take(batch * l.wpart_stride * 8);
   l.total = ndmps::round_up(used, 256);
   return l;
 }
@@ -2957,7 +2965,15 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
   const int kb = std::min<int>(w.kp, kMaxK);
   hipLaunchKernelGGL(trd_invit_kernel, dim3((unsigned)ndmps::ceil_div(w.kp, kMaxK), B), dim3(512),
                      std::max((size_t)n_max * 16, (size_t)2 * 4 * (kb <= 64 ? 32 : 16) * kb * 8), s, desc, w);
-  if (w.kp > kMaxK) {
+  const bool wide_small = w.kp <= kMaxK && wide_layout && d_ws && h_n && wide_layout->kw > 0 && !getenv("NDMPS_ORTHO_NARROW");
+  if (wide_small) {
+    // one or two big matrices: Cholesky-QR across the chip with the rank read on the device (eig_wide.inc)
+    char* base = (char*)d_ws;
+    for (int b = 0; b < batch; ++b)
+      NDMPS_TRY(wide_orthonormalise_auto(desc + b, w.Z + (int64_t)b * w.n_max * w.kp, (int)h_n[b], w.kp,
+                                         (double*)(base + wide_layout->off_ws), (double*)(base + wide_layout->off_wlinv),
+                                         (int)wide_layout->kw, base + wide_layout->off_wgram, wide_layout->wgram_bytes, s));
+  } else if (w.kp > kMaxK) {
     // more than 128 vectors may be wanted: Cholesky-QR across the chip, matrix by matrix (eig_wide.inc)
     NDMPS_REQUIRE(wide_layout && d_ws && h_n && h_k && wide_layout->kw > 0, "wide eigenvector block without its workspace");
     char* base = (char*)d_ws;
@@ -2971,6 +2987,25 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
     hipLaunchKernelGGL(trd_ortho_blocks_kernel, dim3(1, B), dim3(512), (size_t)3 * 64 * 65 * 8, s, desc, w);
   else
     hipLaunchKernelGGL(trd_ortho_kernel<false>, dim3(1, B), dim3(512), (size_t)k16 * (k16 + 1) * 8, s, desc, w);
+  if (wide_small && wide_layout->wpart_stride > 0 && !getenv("NDMPS_BACK_NARROW")) {
+    // one or two big matrices, at most 128 columns: rows dealt to the chip, one launch per block of 64 reflectors
+    double* Tw = (double*)((char*)d_ws + wide_layout->off_wt);
+    double* part = (double*)((char*)d_ws + wide_layout->off_wpart);
+    const int G = n_max >= 2 ? (int)((n_max - 2) / kBwB + 1) : 0;
+    const int chunks = (int)ndmps::ceil_div(n_max, kBrR);
+    const int cols = std::max(kk, k_fill);
+    hipLaunchKernelGGL(back_wide_t_kernel, dim3((unsigned)std::max(G, 1), B), dim3(256), 0, s, (const TrdDesc*)desc, w, Tw,
+                       wide_layout->wt_stride);
+    hipLaunchKernelGGL(back_rows_init_kernel, dim3(256, B), dim3(256), 0, s, (const TrdDesc*)desc, w, k_fill);
+    const dim3 grid((unsigned)chunks, (unsigned)ndmps::ceil_div(cols, kBrC), B);
+    for (int g = G; g >= 0; --g)  // launch g: apply block g (none at first), form block g - 1 (none at last)
+      hipLaunchKernelGGL(back_rows_step_kernel, grid, dim3(256), 0, s, (const TrdDesc*)desc, w, (const double*)Tw,
+                         wide_layout->wt_stride, part, wide_layout->wpart_stride, chunks, g < G ? g : -1, g - 1);
+    hipLaunchKernelGGL(back_rows_sign_kernel, dim3((unsigned)ndmps::ceil_div(cols, 16), B), dim3(1024), 0, s, (const TrdDesc*)desc);
+    ndmps::span_end(vec_span, s, ndmps::kSpanEigenVectors, G + 8, 0);
+    NDMPS_LAUNCH_CHECK();
+    return NDMPS_OK;
+  }
   if (w.kp > kMaxK && !getenv("NDMPS_BACK_NARROW")) {
     // many columns: the reflectors in blocks of 64 on the MFMA, one workgroup per 16 columns (eig_wide.inc)
     double* Tw = (double*)((char*)d_ws + wide_layout->off_wt);
@@ -3035,7 +3070,7 @@ extern "C" int ndmps_syevd_topk_vectors_auto_f64(int batch, const int64_t* h_n, 
   const int kk = (int)std::min(k_cap, n_max);
   hipLaunchKernelGGL(trd_rank_kernel, dim3(batch), dim3(128), 0, s, desc, kk, cutoff, d_ranks, d_spectra, spectra_stride);
   NDMPS_LAUNCH_CHECK();
-  NDMPS_TRY(trd_launch_vectors(batch, n_max, kk, kk, desc, w, s));
+  NDMPS_TRY(trd_launch_vectors(batch, n_max, kk, kk, desc, w, s, &l, d_ws, h_n));
   if (d_status) {
     hipLaunchKernelGGL(trd_status_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, desc, batch, d_status);
     NDMPS_LAUNCH_CHECK();

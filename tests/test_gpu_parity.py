@@ -766,6 +766,21 @@ def test_topk_solver_batch_of_mixed_sizes_and_ranks():
         _check_topk(g, w, v, k, k_max=128)
 
 
+def test_topk_solver_batches_beyond_the_narrow_teams():
+    """More matrices than 8-column teams fit the chip at once (batch * n / 8 workgroups > the resident slots) take
+    32-column blocks that meet at a counter: 20 matrices of order 260, and 9 of order 512."""
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    for n, count, k in ((260, 20, 16), (512, 9, 32)):
+        assert count * -(-n // 8) > lib.ndmps_syevd_topk_team_slots(n) > 0
+        mats = []
+        for _ in range(count):
+            a = rng.standard_normal((n + 16, n)) * np.logspace(0, -4, n)[None, :]
+            mats.append(a.T @ a)
+        for g, (w, v) in zip(mats, _topk(lib, mats, [k] * count)):
+            _check_topk(g, w, v, k)
+
+
 def test_topk_solver_orders_above_512_in_mixed_batches():
     """Orders above 512 (BASELINE config 5: 2048; chi = 128 on a 256^3 volume: 1024) take the column launches;
     batches mix big and small members."""
