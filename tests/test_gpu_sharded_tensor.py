@@ -247,3 +247,28 @@ def test_from_volume_sharded_equals_from_tensor():
     assert mps.bond_sizes() == ref.bond_sizes()
     a, b = mps.to_dense(), ref.mps.to_dense()
     assert float((a - b).norm() / b.norm()) <= 2e-5
+
+
+def test_bench_config_5_on_two_ranks_sharing_the_gpu():
+    """The driver's multi-GPU line for BASELINE config 5 (strong scaling: ONE tensor, its top-level blocks dealt to the
+    ranks, the Gram matrices all-reduced), rehearsed the way this box allows: two ranks over gloo, both on cuda:0
+    (bench.py --share-gpu).  Rank 0 prints one JSON line; its reconstruction check against the single-GPU sweep is
+    part of the run (bench.py raises if the sharded result is off)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--config", "5", "--gpus", "2", "--backend", "gloo",
+           "--share-gpu", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-configs", "--skip-single"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["workload"].startswith("ONE 128x128x64x256")
