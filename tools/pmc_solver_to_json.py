@@ -6,8 +6,9 @@ what they say -- vector instructions per wave, the share of a wave's cycles spen
 barrier) and stalled at issue (SQ_WAIT_INST_ANY), GPU-active cycles per dispatch (GRBM_GUI_ACTIVE is summed over the
 8 XCDs: / 8 / 2.4 GHz ~ the dispatch's wall time in us at full clock).
 
-usage: python tools/pmc_solver_to_json.py PMC_DIR "command that was profiled" out.json [kernel,kernel,...]
-(entries of an existing out.json for other kernels are kept)"""
+usage: python tools/pmc_solver_to_json.py PMC_DIR "command that was profiled" out.json [kernel,kernel,...] [suffix]
+(entries of an existing out.json for other kernels are kept; `suffix` is appended to the keys, e.g. " @ order 2048",
+so that one kernel profiled on two workloads keeps both entries)"""
 import collections
 import csv
 import glob
@@ -17,7 +18,8 @@ import sys
 
 KEEP = ("trd_team_kernel", "trd_tail_kernel", "trd_tail_reg_kernel", "trd_bisect_kernel", "trd_invit_kernel", "trd_ortho_kernel",
         "trd_ortho_blocks_kernel", "trd_back_kernel", "trd_column_kernel", "pnl_vec_kernel", "pnl_symv_kernel", "pnl_update_kernel",
-        "wide_trsm_kernel", "wide_chol_diag_kernel", "wide_chol_trail_kernel", "back_wide_kernel", "blk_step_kernel")
+        "wide_trsm_kernel", "wide_chol_diag_kernel", "wide_chol_trail_kernel", "back_wide_kernel", "blk_step_kernel",
+        "back_rows_step_kernel", "back_wide_t_kernel")
 
 
 def main():
@@ -30,6 +32,7 @@ def main():
             a[1] += 1
     path = sys.argv[3]
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
+    suffix = sys.argv[5] if len(sys.argv) > 5 else ""
     out = {}
     if os.path.exists(path):
         with open(path) as fh:
@@ -53,7 +56,7 @@ def main():
             e["share_of_wave_cycles_stalled_at_issue"] = c.get("SQ_WAIT_INST_ANY", 0.0) / wc
         if "GRBM_GUI_ACTIVE" in c:
             e["gpu_active_us_per_dispatch_at_2.4GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / 2400.0
-        out[key] = e
+        out[key + suffix] = e
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk not in ("command", "kernel")} for k, v in out.items()}, indent=1)[:6000])
