@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace ndmps
 
-extern "C" int ndmps_version(void) { return 103; }  // round 3: + lane-sum hook, fused sweep takes the sorted row tables, streamed 64-column projection
+extern "C" int ndmps_version(void) { return 104; }  // round 4: direct solver for any k <= n <= 4096, potrf, per-slice SSIM, team slots
 
 extern "C" const char* ndmps_last_error(void) { return ndmps::g_err; }
 
