@@ -35,6 +35,16 @@
 #include "lanes.h"
 
 namespace {
+// `ok ? *p : 0` with the load issued unconditionally (p must be a valid address either way): a load under a condition
+// is a branch of its own with a wait behind it, and a kernel that fetches its operands that way fetches them one by one
+// (back_rows_step_kernel: 176 loads, 66 waits, 25 us per launch)
+__device__ __forceinline__ double load_if(const double* p, bool ok) {
+  const double v = *p;
+  return ok ? v : 0.0;
+}
+}  // namespace
+
+namespace {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -595,7 +605,9 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
         // within a fraction of a microsecond of each other.  A team inside one XCD polls everything at once (one round
         // trip less; its polls stay in that XCD's L2).
         constexpr bool kScalarsFirst = NR >= 4;
-        static_assert(!TAGGED || CW == 8, "32-column blocks (128 registers of matrix per thread) have no room for the records in flight");
+        // 32-column blocks keep the counter: their tagged variant (128 registers of matrix per thread) spills under the
+        // 256-register cap of two workgroups per CU, and every spilling build of it waited out its 3 s (round 4, twice)
+        static_assert(!TAGGED || CW == 8, "tagged records: 8-column blocks only");
         bool ok = !kScalarsFirst;
         for (unsigned polls = 1; !ok; ++polls) {
           team_u32x4 qj, qj1, qx1;
@@ -780,7 +792,8 @@ trd_team_kernel(TrdDesc* __restrict__ desc, TrdWork w, int b0, unsigned epoch) {
       if (p == kk / 4) {
         double* out = xc + ((j + 1) & 1) * lda;
         // the column's sixteen values first (one unrolled copy per column slot: a run-time register index would
-        // send the tiles to scratch), then one store loop
+        // send the tiles to scratch), then one store loop (storing straight from the tiles, one loop per slot, costs
+        // the 32-column kernel 190 spilled registers)
         double colv[NT];
 #define NDMPS_TEAM_PICK(KS) _Pragma("unroll") for (int u = 0; u < NT; ++u) colv[u] = a[u][KS];
         switch (kk % 4) {
@@ -1605,6 +1618,8 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
             dst[1][u] = ok ? DL[o] : 0.0;
             dst[2][u] = (ok && PV[o] != 0) ? 1.0 : 0.0;
           }
+          // (unconditional loads with a select behind them -- load_if -- change nothing here at order 512 and cost 0.5 ms
+          // at order 2048: the recurrence, not the helpers' fetch, is what a block waits for)
         }
       };
       auto commit = [&](int blk, const double (&src)[3][EPT]) {
