@@ -74,6 +74,37 @@ def test_library_exports_every_declared_symbol():
     assert lib.ndmps_version() >= 100
 
 
+def test_resident_kernels_keep_their_state_in_registers():
+    """The resident tridiagonalisation holds its share of the matrix in registers for the life of a launch and spins on
+    agent-scope loads written in inline assembly; a build whose register allocation spills part of that state to
+    scratch is slower at best (every column then pays a scratch round trip) and, in round 4, waited out its 3 s bound
+    (two builds of a tagged 32-column variant, removed).  The code object says how every kernel was allocated: no
+    instantiation of `trd_team_kernel`, nor the row-dealt back-transformation, may spill a vector register."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("no ROCm LLVM tools on this host")
+    tmp = tempfile.mkdtemp()
+    try:
+        shutil.copy(_lib.LIB_PATH, os.path.join(tmp, "g.so"))
+        subprocess.run([objdump, "--offloading", "g.so"], cwd=tmp, capture_output=True, check=True)
+        seen = {}
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            notes = subprocess.run([readelf, "--notes", f], cwd=tmp, capture_output=True, text=True).stdout
+            for name, spills in re.findall(r"\.name:\s+(\S+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+                if "trd_team_kernel" in name or "back_rows_step_kernel" in name:
+                    seen[name] = int(spills)
+    finally:
+        shutil.rmtree(tmp)
+    assert len([k for k in seen if "trd_team_kernel" in k]) >= 4, sorted(seen)
+    assert all(v == 0 for v in seen.values()), seen
+
+
 def _emulate(shape, mode):
     lib = _lib.load()
     f, _ = hc.get_factorlist(shape)
