@@ -21,6 +21,14 @@
 // product and no cross-lane reduction is needed).  Every workgroup recomputes the O(n) vector part
 // (previous step's w, this step's reflector) redundantly and bit-identically.  When the trailing matrix
 // fits the LDS (<= 128 x 128) one workgroup per matrix finishes the reduction without further launches.
+// That launch-per-column structure (trd_column_kernel) is the fall-back now.  Routes of trd_reduce_and_values:
+//   orders <= 2048 whose teams fit the chip   trd_team_kernel: the matrix resident in registers, one launch, one
+//                                             exchange between the workgroups of a matrix per column
+//   above (even, uniform orders)              panel-blocked launches (eig_panel.inc), the last 2048 / 1024 / 512
+//                                             columns in the resident kernel
+//   everything else, recovery                 panel-blocked launches to the end (from order 1536), column launches
+// and of the eigenvectors: one workgroup per matrix (lockstep groups), or across the chip (eig_wide.inc) for more
+// than 128 vectors and for one or two matrices of order >= 1024.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

@@ -244,7 +244,9 @@ int ndmps_syevj_batched_vectors_f64(int batch, double* d_G, int64_t stride_G, co
  * exact sweeps and compress() want all eigenpairs above a cutoff (core/ndmps.py:74,104-106: dgesdd through quimb).
  * Above ndmps_syevd_topk_max_k() wanted vectors the eigenvectors of T are iterated in column blocks of 128 and
  * orthonormalised across the chip (Gram matrix on the fp64 MFMA, blocked Cholesky, one-launch triangular solve:
- * csrc/eig_wide.inc).  Orders from 1536 on are tridiagonalised panel by panel (csrc/eig_panel.inc). */
+ * csrc/eig_wide.inc), and so are the vectors of one or two matrices of order >= 1024.  Tridiagonalisation: orders up to
+ * 2048 whose teams fit the chip together stay resident in registers for all columns (one launch); above that, panel by
+ * panel (csrc/eig_panel.inc) with the last 2048 / 1024 / 512 columns handed to the resident kernel. */
 int64_t ndmps_syevd_topk_max_n(void);
 int64_t ndmps_syevd_topk_max_k(void);
 int64_t ndmps_syevd_topk_max_k_wide(void);
@@ -262,10 +264,10 @@ int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t stride_G, 
                                 int64_t k_max, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream);
 int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const int64_t* h_k, int64_t k_max,
                                  void* d_ws, int64_t ws_bytes, int* h_status, ndmps_stream_t stream);
-/* The resident tridiagonalisation (orders 129..512, one launch for all columns of every matrix) makes the workgroups
+/* The resident tridiagonalisation (orders 129..2048, one launch for all columns of every matrix) makes the workgroups
  * of a matrix wait for each other; every wait is bounded (3 s) and a team that gave up leaves status 2.
  * _recover_f64: call after _values_f64 with the same batch / sizes / workspace where the host synchronises anyway:
- * waits for `stream`; if any matrix carries status 2, phase 1 is done again for the batch on the per-column launches
+ * waits for `stream`; if any matrix carries status 2, phase 1 is done again for the batch on the per-column / panel launches
  * (asynchronous), *h_recovered (may be NULL) = 1.  _set_team(0 / 1): resident launch off / on for the calling host
  * thread, returns the previous setting.  _team_fallbacks: how often a resident launch was given up and redone
  * (process-wide); _note_team_fallback: for callers that repeat a sequence of their own.
