@@ -1389,6 +1389,16 @@ __device__ __forceinline__ void tile_store(double* M, int r0, int c0, int ld, in
   for (int r = 0; r < 4; ++r) M[(r0 + lk + 4 * r) * ld + c0 + li] = t[r];
 }
 
+// the value lane `l` (wave-uniform, here always a constant of an unrolled loop) holds: two v_readlane_b32 into scalar
+// registers instead of the two ds_bpermute_b32 of __shfl -- the diagonal tiles below broadcast 270 doubles each, one
+// after the other (45 us of a 64 x 64 factorisation were those LDS round trips)
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Blocked Cholesky S = L L^T and L^-1 for k16 <= 64 in LDS (S, then L, in the lower triangle of Ls; L^-1 in Li,
 // both [k16][ld]); 16 x 16 tiles, diagonal tiles by one wave in registers (lane = row, shuffles broadcast the
 // pivots), panels / trailing updates / inverse blocks on the f64 MFMA, three barriers per tile column.  Eight
@@ -1412,7 +1422,7 @@ __device__ bool chol_inv_blocked(double* Ls, double* Li, int k16, int kk, int ld
       for (int c = 0; c < 16; ++c) row[c] = lane < 16 ? Ls[(j0 + lane) * ld + j0 + c] : 0.0;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const double piv = __shfl(row[c], c, 64);
+        const double piv = readlane_f64(row[c], c);
         double rs = 1.0;
         if (piv > 0.0) rs = fast_rsqrt<2>(piv);
         else if (lane == 0) bad = 1;
@@ -1420,7 +1430,7 @@ __device__ bool chol_inv_blocked(double* Ls, double* Li, int k16, int kk, int ld
         row[c] = lc;
 #pragma unroll
         for (int cc = c + 1; cc < 16; ++cc) {
-          const double lcc = __shfl(lc, cc, 64);
+          const double lcc = readlane_f64(lc, cc);
           row[cc] = fma(-lc, lcc, row[cc]);
         }
       }
@@ -1435,10 +1445,10 @@ __device__ bool chol_inv_blocked(double* Ls, double* Li, int k16, int kk, int ld
         double sum = lane == i ? 1.0 : 0.0;
 #pragma unroll
         for (int pz = 0; pz < i; ++pz) {
-          const double lip = __shfl(row[pz], i, 64);  // L[i][pz]
+          const double lip = readlane_f64(row[pz], i);  // L[i][pz]
           sum = fma(-lip, x[pz], sum);
         }
-        const double lii = __shfl(row[i], i, 64);
+        const double lii = readlane_f64(row[i], i);
         x[i] = lane <= i ? sum * fast_rcp<2>(lii) : 0.0;
       }
       if (lane < 16) {
