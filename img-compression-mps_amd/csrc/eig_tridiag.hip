@@ -1502,7 +1502,10 @@ __device__ bool chol_inv_blocked(double* Ls, double* Li, int k16, int kk, int ld
   return bad == 0;
 }
 
-// One workgroup (512 threads) per matrix.  Threads c < k factor T - lam_c I (pivoted, dgttrf order) and solve
+// rows per block of the sweeps' LDS ring: SB kb <= 2048 doubles per operand array (six arrays + two out-buffers: 128 KB)
+__host__ __device__ constexpr int invit_rows_per_block(int kb) { return kb <= 16 ? 128 : kb <= 32 ? 64 : kb <= 64 ? 32 : 16; }
+
+// One workgroup (512 threads) per matrix and column block.  Threads c < k factor T - lam_c I (pivoted, dgttrf order) and solve
 // twice from a random start; no orthogonalisation in between (columns of a numerically multiple eigenvalue
 // stay independent because their starts are), then the whole workgroup orthonormalises the block twice:
 // S = Z^T Z (f64 MFMA from global), Cholesky in LDS, Z <- Z L^-T row by row.  Measured on the CPU prototype
@@ -1511,14 +1514,15 @@ __device__ bool chol_inv_blocked(double* Ls, double* Li, int k16, int kk, int ld
 // the columns of a multiple eigenvalue more parallel and costs a digit.
 // The recurrences are sequential in i and run on k <= 128 lanes: their operands are fetched one chunk of
 // CH steps ahead of the chain that consumes them (a global access costs more than a chunk of the chain).
-__global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ desc, TrdWork w) {
+__global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ desc, TrdWork w, int cb) {
   TrdDesc& d = desc[blockIdx.y];
   const int n = d.n, k = d.k, kp = w.kp;
   const int tid = threadIdx.x;
-  // column block of this workgroup: all kp <= 128 columns, or columns [128 x, 128 x + 128) of a wider block (k > 128:
-  // every eigenpair wanted, exact sweeps); kb: width of the block's tiles in LDS, kl: wanted columns inside it
-  const int cbase = (int)blockIdx.x * kMaxK;
-  const int kb = min(kp - cbase, kMaxK), kl = max(min(k - cbase, kMaxK), 0);
+  // column block of this workgroup: columns [cb x, cb x + cb) of the kp columns (cb = 128: one block for up to 128 wanted
+  // vectors; narrower blocks deal the columns of one or a few big matrices to several CUs, invit_block_width); kb: width
+  // of the block's tiles in LDS, kl: wanted columns inside it
+  const int cbase = (int)blockIdx.x * cb;
+  const int kb = min(kp - cbase, cb), kl = max(min(k - cbase, cb), 0);
   if (kb <= 0) return;
   const int64_t b = blockIdx.y;
   const double* dd = w.d + b * w.n_max;
@@ -1601,8 +1605,8 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   // values per row and lane, the division of the back substitution folded into them), and carry the results of
   // the block before from an LDS out-buffer back to Z with coalesced stores.
   {
-    const int SB = kb <= 64 ? 32 : 16;
-    const int per_arr = SB * kb;               // doubles per operand array and block (2048)
+    const int SB = invit_rows_per_block(kb);
+    const int per_arr = SB * kb;               // doubles per operand array and block (<= 2048)
     constexpr int HN = 384, EPT = 6;           // helper threads, elements per helper and array (EPT HN >= per_arr)
     double* ring = lds;                         // [2][3][per_arr]
     double* outb = lds + 6 * per_arr;           // [2][per_arr]
@@ -2985,6 +2989,64 @@ extern "C" int ndmps_syevd_topk_values_f64(int batch, const double* d_G, int64_t
 }
 
 namespace {
+// A stream per device for work that depends only on phase 1 and is needed late in phase 2 (the T factors of the blocked
+// back-transformations: 0.37 ms at order 2048 while inverse iteration and orthonormalisation keep a handful of CUs busy).
+// fork: the side stream waits for what `s` holds so far; join: `s` waits for what the side stream was given since.
+struct SideFork {
+  hipStream_t side = nullptr;
+  hipEvent_t done = nullptr;
+};
+int side_stream(hipStream_t& out) {
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  int dev = 0;
+  NDMPS_CHECK_HIP(hipGetDevice(&dev));
+  NDMPS_REQUIRE(dev >= 0 && dev < 64, "device index %d outside [0, 64)", dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!streams[dev]) NDMPS_CHECK_HIP(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
+  out = streams[dev];
+  return NDMPS_OK;
+}
+int side_fork(hipStream_t s, SideFork& f) {
+  if (getenv("NDMPS_NO_SIDE_STREAM")) return NDMPS_OK;  // f.side stays null: the caller launches on `s`
+  hipStream_t side = nullptr;
+  NDMPS_TRY(side_stream(side));
+  hipEvent_t here = nullptr;
+  NDMPS_CHECK_HIP(hipEventCreateWithFlags(&here, hipEventDisableTiming));
+  NDMPS_CHECK_HIP(hipEventRecord(here, s));
+  NDMPS_CHECK_HIP(hipStreamWaitEvent(side, here, 0));
+  NDMPS_CHECK_HIP(hipEventDestroy(here));  // released once it has completed
+  f.side = side;
+  return NDMPS_OK;
+}
+int side_join(hipStream_t s, SideFork& f) {
+  if (!f.side) return NDMPS_OK;
+  NDMPS_CHECK_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+  NDMPS_CHECK_HIP(hipEventRecord(f.done, f.side));
+  NDMPS_CHECK_HIP(hipStreamWaitEvent(s, f.done, 0));
+  NDMPS_CHECK_HIP(hipEventDestroy(f.done));
+  f.side = nullptr;
+  return NDMPS_OK;
+}
+
+// Width of the column blocks of the inverse iteration.  The recurrences of a column are a dependent chain over the rows
+// whatever the width; what a block's ONE CU adds is the traffic of its helpers -- three operand arrays in, one out per sweep
+// and column, 8.4 MB per sweep at order 2048 with 128 columns, at the 30 - 60 GB/s a single CU gets.  From order 1024 on the
+// columns go to as many CUs as the launch leaves free (blocks of 16 at least); lockstep groups of order <= 512 keep one
+// block per matrix (their CUs are wanted by the other group's kernels).  NDMPS_INVIT_CB=16|32|64|128 forces a width.
+int invit_block_width(int batch, int64_t n_max, int kp) {
+  static const int forced = [] {
+    const char* e = getenv("NDMPS_INVIT_CB");
+    const int v = e ? atoi(e) : 0;
+    return (v == 16 || v == 32 || v == 64 || v == 128) ? v : 0;
+  }();
+  if (forced) return forced;
+  if (n_max < 1024) return kMaxK;
+  int cb = kMaxK;
+  while (cb > 16 && (int64_t)batch * ndmps::ceil_div(kp, cb / 2) <= 256) cb /= 2;
+  return cb;
+}
+
 // inverse iteration + back-transformation for ranks already stored in the descriptors; kk: largest rank any
 // matrix may have (sizes the launches), k_fill: columns zero-filled beyond a matrix's rank
 int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* desc, const TrdWork& w, hipStream_t s,
@@ -2993,11 +3055,24 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
   const unsigned B = (unsigned)batch;
   const int k16 = (kk + 15) & ~15;
   void* vec_span = ndmps::span_begin(s);
+  // the T factors of a blocked back-transformation need the reflectors only: on the side stream, beside everything up to
+  // the orthonormalisation
+  const bool blocked_back = wide_layout && d_ws && wide_layout->kw > 0 && !getenv("NDMPS_BACK_NARROW") &&
+                            (w.kp > kMaxK || (h_n && wide_layout->wpart_stride > 0 && !getenv("NDMPS_ORTHO_NARROW")));
+  SideFork fork;
+  if (blocked_back) {
+    NDMPS_TRY(side_fork(s, fork));
+    hipLaunchKernelGGL(back_wide_t_kernel, dim3((unsigned)ndmps::ceil_div(std::max<int64_t>(n_max - 1, 1), kBwB), B), dim3(256), 0,
+                       fork.side ? fork.side : s, (const TrdDesc*)desc, w, (double*)((char*)d_ws + wide_layout->off_wt),
+                       wide_layout->wt_stride);
+  }
   hipLaunchKernelGGL(trd_shift_kernel, dim3((unsigned)ndmps::ceil_div(batch, 64)), dim3(64), 0, s, desc, w, batch);
-  // inverse iteration in column blocks of kMaxK (one block up to 128 wanted vectors)
-  const int kb = std::min<int>(w.kp, kMaxK);
-  hipLaunchKernelGGL(trd_invit_kernel, dim3((unsigned)ndmps::ceil_div(w.kp, kMaxK), B), dim3(512),
-                     std::max((size_t)n_max * 16, (size_t)2 * 4 * (kb <= 64 ? 32 : 16) * kb * 8), s, desc, w);
+  // inverse iteration in column blocks (invit_block_width: one block of up to 128 vectors per matrix of a lockstep group,
+  // narrow blocks on their own CUs for one or a few big matrices)
+  const int cb = invit_block_width(batch, n_max, w.kp);
+  const int kb = std::min<int>(w.kp, cb);
+  hipLaunchKernelGGL(trd_invit_kernel, dim3((unsigned)ndmps::ceil_div(w.kp, cb), B), dim3(512),
+                     std::max((size_t)n_max * 16, (size_t)2 * 4 * invit_rows_per_block(kb) * kb * 8), s, desc, w, cb);
   const bool wide_small = w.kp <= kMaxK && wide_layout && d_ws && h_n && wide_layout->kw > 0 && !getenv("NDMPS_ORTHO_NARROW");
   if (wide_small) {
     // one or two big matrices: Cholesky-QR across the chip with the rank read on the device (eig_wide.inc)
@@ -3027,8 +3102,7 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
     const int G = n_max >= 2 ? (int)((n_max - 2) / kBwB + 1) : 0;
     const int chunks = (int)ndmps::ceil_div(n_max, kBrR);
     const int cols = std::max(kk, k_fill);
-    hipLaunchKernelGGL(back_wide_t_kernel, dim3((unsigned)std::max(G, 1), B), dim3(256), 0, s, (const TrdDesc*)desc, w, Tw,
-                       wide_layout->wt_stride);
+    NDMPS_TRY(side_join(s, fork));
     hipLaunchKernelGGL(back_rows_init_kernel, dim3(256, B), dim3(256), 0, s, (const TrdDesc*)desc, w, k_fill);
     const dim3 grid((unsigned)chunks, (unsigned)ndmps::ceil_div(cols, kBrC), B);
     for (int g = G; g >= 0; --g)  // launch g: apply block g (none at first), form block g - 1 (none at last)
@@ -3042,8 +3116,7 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
   if (w.kp > kMaxK && !getenv("NDMPS_BACK_NARROW")) {
     // many columns: the reflectors in blocks of 64 on the MFMA, one workgroup per 16 columns (eig_wide.inc)
     double* Tw = (double*)((char*)d_ws + wide_layout->off_wt);
-    hipLaunchKernelGGL(back_wide_t_kernel, dim3((unsigned)ndmps::ceil_div(std::max<int64_t>(n_max - 1, 1), kBwB), B), dim3(256), 0, s,
-                       (const TrdDesc*)desc, w, Tw, wide_layout->wt_stride);
+    NDMPS_TRY(side_join(s, fork));
     hipLaunchKernelGGL(back_wide_kernel, dim3((unsigned)ndmps::ceil_div(kk, kBwC), B), dim3(64 * kBwWaves), 0, s, (const TrdDesc*)desc, w,
                        (const double*)Tw, wide_layout->wt_stride);
     ndmps::span_end(vec_span, s, ndmps::kSpanEigenVectors, 4, 0);

@@ -110,6 +110,34 @@ __global__ void __launch_bounds__(256) minmax_final_kernel(const float* __restri
   }
 }
 
+// Pointer / length tables of a many-tensor reduction, handed over as KERNEL ARGUMENTS (32 entries per launch) like the
+// rank tables of the sweep: no hipMemcpyAsync from pageable host memory (which stages through a pinned buffer and may
+// wait for the stream) on the way to a launch whose result the caller reads back at once.
+constexpr int kManyChunk = 32;
+struct ManyChunk {
+  const void* ptr[kManyChunk];
+  int64_t len[kManyChunk];
+};
+__global__ void many_set_kernel(const void** __restrict__ d_ptrs, int64_t* __restrict__ d_lens, ManyChunk c, int base, int n) {
+  const int t = threadIdx.x;
+  if (t < n) {
+    d_ptrs[base + t] = c.ptr[t];
+    d_lens[base + t] = c.len[t];
+  }
+}
+static void many_upload(const void** d_ptrs, int64_t* d_lens, const void* const* h_ptrs, const int64_t* h_lens, int count,
+                        hipStream_t s) {
+  for (int base = 0; base < count; base += kManyChunk) {
+    ManyChunk c;
+    const int n = std::min(kManyChunk, count - base);
+    for (int t = 0; t < kManyChunk; ++t) {
+      c.ptr[t] = t < n ? h_ptrs[base + t] : nullptr;
+      c.len[t] = t < n ? h_lens[base + t] : 0;
+    }
+    hipLaunchKernelGGL(many_set_kernel, dim3(1), dim3(kManyChunk), 0, s, d_ptrs, d_lens, c, base, n);
+  }
+}
+
 // many small tensors at once: blockIdx.y = tensor, blockIdx.x = slice; partial (min, max, sum of
 // squares in fp64) per slice, as three doubles
 __global__ void __launch_bounds__(256)
@@ -548,8 +576,7 @@ extern "C" int ndmps_minmax_many_f32(int count, const float* const* h_ptrs, cons
   const float** d_ptrs = (const float**)base;
   int64_t* d_lens = (int64_t*)(base + ndmps::round_up((int64_t)count * 8, 256));
   double* partial = (double*)((char*)d_lens + ndmps::round_up((int64_t)count * 8, 256));
-  NDMPS_CHECK_HIP(hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(float*) * count, hipMemcpyHostToDevice, s));
-  NDMPS_CHECK_HIP(hipMemcpyAsync(d_lens, h_lens, sizeof(int64_t) * count, hipMemcpyHostToDevice, s));
+  many_upload((const void**)d_ptrs, d_lens, (const void* const*)h_ptrs, h_lens, count, s);
   hipLaunchKernelGGL(minmax_many_kernel, dim3(kManySlices, count), dim3(256), 0, s, d_ptrs, d_lens, partial);
   NDMPS_LAUNCH_CHECK();
   std::vector<double> host((size_t)count * kManySlices * 3);
@@ -688,8 +715,7 @@ extern "C" int ndmps_minmax_many_f64(int count, const double* const* h_ptrs, con
   const double** d_ptrs = (const double**)base;
   int64_t* d_lens = (int64_t*)(base + ndmps::round_up((int64_t)count * 8, 256));
   double* partial = (double*)((char*)d_lens + ndmps::round_up((int64_t)count * 8, 256));
-  NDMPS_CHECK_HIP(hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(double*) * count, hipMemcpyHostToDevice, s));
-  NDMPS_CHECK_HIP(hipMemcpyAsync(d_lens, h_lens, sizeof(int64_t) * count, hipMemcpyHostToDevice, s));
+  many_upload((const void**)d_ptrs, d_lens, (const void* const*)h_ptrs, h_lens, count, s);
   hipLaunchKernelGGL(minmax_many_f64_kernel, dim3(kManySlices, count), dim3(256), 0, s, d_ptrs, d_lens, partial);
   NDMPS_LAUNCH_CHECK();
   std::vector<double> host((size_t)count * kManySlices * 3);

@@ -83,6 +83,8 @@ __global__ void tail_norm_reduce_kernel(const double* __restrict__ partial, int 
   out[j] = s;
 }
 
+__global__ void set_scalar_f64_kernel(double* p, double v) { *p = v; }
+
 template <typename T = float>
 __global__ void __launch_bounds__(256) f32_to_f64_kernel(const T* __restrict__ x, int64_t n, double* y) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -1881,9 +1883,7 @@ int overlap_impl(int L, const int64_t* h_dims, const int64_t* h_bonds_a, const T
   double* X = ar.take<double>(xmax);
   NDMPS_REQUIRE(E[0] && E[1] && A && B && X, "workspace carve failed");
 
-  const double one = 1.0;
-  NDMPS_CHECK_HIP(hipMemcpyAsync(E[0], &one, sizeof(double), hipMemcpyHostToDevice, s));
-  NDMPS_CHECK_HIP(hipStreamSynchronize(s));  // `one` lives on this stack frame
+  hipLaunchKernelGGL(set_scalar_f64_kernel, dim3(1), dim3(1), 0, s, E[0], 1.0);  // no copy from pageable host memory
   int cur = 0;
   for (int i = 0; i < L; ++i) {
     const int64_t ca = h_bonds_a[i], ca2 = h_bonds_a[i + 1];
