@@ -1514,7 +1514,8 @@ __host__ __device__ constexpr int invit_rows_per_block(int kb) { return kb <= 16
 // the columns of a multiple eigenvalue more parallel and costs a digit.
 // The recurrences are sequential in i and run on k <= 128 lanes: their operands are fetched one chunk of
 // CH steps ahead of the chain that consumes them (a global access costs more than a chunk of the chain).
-__global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ desc, TrdWork w, int cb) {
+__global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ desc, TrdWork w, int cb_arg) {
+  const int cb = cb_arg & 0xffff, dbg = cb_arg >> 16;  // dbg: ablation switches of tools/scratch (0 in the product)
   TrdDesc& d = desc[blockIdx.y];
   const int n = d.n, k = d.k, kp = w.kp;
   const int tid = threadIdx.x;
@@ -1533,7 +1534,6 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   double* DI = DL + plane;
   double* DU = DI + plane;
   double* DU2 = DU + plane;
-  unsigned char* PV = w.piv + b * plane;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const double bound = w.bound[b];
   const double inv = bound > 0.0 ? 1.0 / bound : 0.0;
@@ -1574,18 +1574,21 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
           const double du_i = swap ? dn : ui;
           const double up = swap ? ui : dn;
           const int64_t o = (int64_t)i * kp + c;
+          // stored as the sweeps use them (their helpers load and pass on, no arithmetic between a load and LDS): the
+          // division of the back substitution folded into du, du2 and z; the row interchange rides in the lowest
+          // mantissa bit of 1 / d (a scale factor: one ulp of it is a rounding like any other)
+          const double rs = __hiloint2double(__double2hiint(rp), (__double2loint(rp) & ~1) | (swap ? 1 : 0));
           DL[o] = fact;
-          DI[o] = rp;
-          DU[o] = du_i;
-          DU2[o] = swap ? un : 0.0;
-          PV[o] = swap ? 1 : 0;
+          DI[o] = rs;
+          DU[o] = du_i * rs;
+          DU2[o] = swap ? un * rs : 0.0;
           di = fma(-fact, du_i, up);
           ui = swap ? -fact * un : un;
           li = t0[u].y;                                      // e_{i+1}: sub-diagonal below row i + 1
           const double xn = hash_uniform((unsigned)(i + 1), (unsigned)c);
           const double top = swap ? xn : xi;
           const double bot = swap ? xi : xn;
-          Z[o] = top;
+          Z[o] = top * rs;
           xi = fma(-fact, top, bot);
         }
       }
@@ -1604,44 +1607,49 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
   // operands of a block of SB rows from global memory into a double-buffered LDS ring two blocks ahead (three
   // values per row and lane, the division of the back substitution folded into them), and carry the results of
   // the block before from an LDS out-buffer back to Z with coalesced stores.
+  // The direction is a compile-time constant of the sweep's body (two copies), and a group of CH rows that lies inside
+  // the matrix runs without its range selects: with `backward` and the range tested per row the ISA of a row was 40
+  // instructions and two branches around its two FMAs (100 ns per row; now the chain and its LDS traffic).
   {
     const int SB = invit_rows_per_block(kb);
     const int per_arr = SB * kb;               // doubles per operand array and block (<= 2048)
     constexpr int HN = 384, EPT = 6;           // helper threads, elements per helper and array (EPT HN >= per_arr)
     double* ring = lds;                         // [2][3][per_arr]
     double* outb = lds + 6 * per_arr;           // [2][per_arr]
-    double st0[3][EPT], st1[3][EPT];            // two register stages x 3 arrays
     const bool solver = tid < kl;
     const bool helper = tid >= 128;
     const int ht = tid - 128;
     const int c = cbase + tid;
     double xi = solver ? Z[(int64_t)(n - 1) * kp + c] : 0.0;  // last component of the fused first forward sweep
-    for (int sweep = 0; sweep < 3; ++sweep) {
-      const bool backward = sweep != 1;
-      const int rows = n - 1;                   // both recurrences visit rows 0 .. n-2
-      const int nblk = (rows + SB - 1) / SB;
+    const int rows = n - 1;                     // both recurrences visit rows 0 .. n-2
+    const int nblk = (rows + SB - 1) / SB;
+    auto sweep_body = [&](auto back_tag) {
+      constexpr bool backward = decltype(back_tag)::value;
+      double st0[3][EPT], st1[3][EPT];            // two register stages x 3 arrays
       // row visited at position s of block blk (may be out of range: < 0 or > n-2)
       auto row_of = [&](int blk, int s2) { return backward ? (n - 2) - blk * SB - s2 : blk * SB + s2; };
+      // three loads per element from an address inside the arrays whatever the element (rows beyond the matrix and
+      // blocks beyond the last look at row 0: what they fetch is never used -- the chain ignores positions >= valid,
+      // write_back skips them, a block >= nblk is never committed).  No branch and no arithmetic between the loads and
+      // the stage registers: all eighteen are in flight until the next iteration parks them.  (With z / d formed here the
+      // four loads of an element were waited for one element after the other: six memory round trips per block and
+      // helper, 60 of the 146 us of the three sweeps at order 512.)
       auto fetch = [&](int blk, double (&dst)[3][EPT]) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
           const int e = ht + HN * u;
           const int s2 = e / kb, cc = e % kb;
-          const int r = row_of(blk, s2);
-          const bool ok = e < per_arr && blk < nblk && r >= 0 && r <= n - 2;
-          const int64_t o = (int64_t)(ok ? r : 0) * kp + cbase + cc;
-          if (backward) {  // x_r = (z_r - du_r x_{r+1} - du2_r x_{r+2}) / d_r, the division folded in
-            const double di = ok ? DI[o] : 0.0;
-            dst[0][u] = ok ? Z[o] * di : 0.0;
-            dst[1][u] = ok ? DU[o] * di : 0.0;
-            dst[2][u] = ok ? DU2[o] * di : 0.0;
+          const int r = min(max(row_of(blk, s2), 0), n - 2);
+          const int64_t o = (int64_t)((dbg & 2) ? 0 : r) * kp + cbase + cc;
+          if (backward) {  // x_r = z_r / d_r - (du_r / d_r) x_{r+1} - (du2_r / d_r) x_{r+2}
+            dst[0][u] = Z[o];
+            dst[1][u] = DU[o];
+            dst[2][u] = DU2[o];
           } else {
-            dst[0][u] = ok ? Z[o + kp] : 0.0;
-            dst[1][u] = ok ? DL[o] : 0.0;
-            dst[2][u] = (ok && PV[o] != 0) ? 1.0 : 0.0;
+            dst[0][u] = Z[o + kp];
+            dst[1][u] = DL[o];
+            dst[2][u] = DI[o];  // 1 / d_r, lowest mantissa bit set where rows r and r + 1 were interchanged
           }
-          // (unconditional loads with a select behind them -- load_if -- change nothing here at order 512 and cost 0.5 ms
-          // at order 2048: the recurrence, not the helpers' fetch, is what a block waits for)
         }
       };
       auto commit = [&](int blk, const double (&src)[3][EPT]) {
@@ -1662,7 +1670,7 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
           const int e = ht + HN * u;
           const int s2 = e / kb, cc = e % kb;
           const int r = row_of(blk, s2);
-          if (e < per_arr && cc < kl && r >= 0 && r <= n - 2) Z[(int64_t)r * kp + cbase + cc] = ob[e];
+          if (e < per_arr && cc < kl && r >= 0 && r <= n - 2 && !(dbg & 4)) Z[(int64_t)r * kp + cbase + cc] = ob[e];
         }
       };
       double x1 = 0.0, x2 = 0.0;
@@ -1688,9 +1696,10 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
           if (blk + 1 < nblk) commit(blk + 1, parked);
           fetch(blk + 2, refill);
           if (blk >= 1) write_back(blk - 1);
-        } else if (solver) {
+        } else if (solver && !(dbg & 1)) {
           const double* buf = ring + (blk & 1) * 3 * per_arr + tid;
           double* ob = outb + (blk & 1) * per_arr + tid;
+          const int valid = min(SB, rows - blk * SB);  // positions 0 .. valid - 1 of the block are rows of the matrix
           for (int s0 = 0; s0 < SB; s0 += CH) {  // eight rows' operands out of LDS, then eight steps of the chain
             double o0[CH], o1[CH], o2[CH];
 #pragma unroll
@@ -1700,22 +1709,38 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
               o1[u] = buf[per_arr + e];
               o2[u] = buf[2 * per_arr + e];
             }
+            if (s0 + CH <= valid) {  // the whole group inside the matrix (wave-uniform): no selects on the chain
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-              const int r = row_of(blk, s0 + u);
-              const bool in = r >= 0 && r <= n - 2;
-              if (backward) {
-                const double x0 = fma(-o1[u], x1, fma(-o2[u], x2, o0[u]));
-                ob[(s0 + u) * kb] = x0;
-                if (in) {
+              for (int u = 0; u < CH; ++u) {
+                if (backward) {
+                  const double x0 = fma(-o1[u], x1, fma(-o2[u], x2, o0[u]));
+                  ob[(s0 + u) * kb] = x0;
                   x2 = x1;
                   x1 = x0;
+                } else {
+                  const bool sw = (__double2loint(o2[u]) & 1) != 0;
+                  const double top = sw ? o0[u] : xi, bot = sw ? xi : o0[u];
+                  ob[(s0 + u) * kb] = top * o2[u];  // z_r / d_r, what the back substitution reads
+                  xi = fma(-o1[u], top, bot);
                 }
-              } else {
-                const bool sw = o2[u] != 0.0;
-                const double top = sw ? o0[u] : xi, bot = sw ? xi : o0[u];
-                ob[(s0 + u) * kb] = top;
-                if (in) xi = fma(-o1[u], top, bot);
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < CH; ++u) {
+                const bool in = s0 + u < valid;
+                if (backward) {
+                  const double x0 = fma(-o1[u], x1, fma(-o2[u], x2, o0[u]));
+                  ob[(s0 + u) * kb] = x0;
+                  if (in) {
+                    x2 = x1;
+                    x1 = x0;
+                  }
+                } else {
+                  const bool sw = (__double2loint(o2[u]) & 1) != 0;
+                  const double top = sw ? o0[u] : xi, bot = sw ? xi : o0[u];
+                  ob[(s0 + u) * kb] = top * o2[u];
+                  if (in) xi = fma(-o1[u], top, bot);
+                }
               }
             }
           }
@@ -1728,7 +1753,10 @@ __global__ void __launch_bounds__(512) trd_invit_kernel(TrdDesc* __restrict__ de
       }
       if (helper) write_back(nblk - 1);
       __syncthreads();  // the sweep's results are in Z before the next one (or the orthonormalisation) reads them
-    }
+    };
+    sweep_body(std::true_type{});
+    sweep_body(std::false_type{});
+    sweep_body(std::true_type{});
   }
   // pad columns of the block stay zero
   if (kl < kb)
@@ -3072,7 +3100,8 @@ int trd_launch_vectors(int batch, int64_t n_max, int kk, int k_fill, TrdDesc* de
   const int cb = invit_block_width(batch, n_max, w.kp);
   const int kb = std::min<int>(w.kp, cb);
   hipLaunchKernelGGL(trd_invit_kernel, dim3((unsigned)ndmps::ceil_div(w.kp, cb), B), dim3(512),
-                     std::max((size_t)n_max * 16, (size_t)2 * 4 * invit_rows_per_block(kb) * kb * 8), s, desc, w, cb);
+                     std::max((size_t)n_max * 16, (size_t)2 * 4 * invit_rows_per_block(kb) * kb * 8), s, desc, w,
+                     cb | ((getenv("NDMPS_INVIT_DBG") ? atoi(getenv("NDMPS_INVIT_DBG")) : 0) << 16));
   const bool wide_small = w.kp <= kMaxK && wide_layout && d_ws && h_n && wide_layout->kw > 0 && !getenv("NDMPS_ORTHO_NARROW");
   if (wide_small) {
     // one or two big matrices: Cholesky-QR across the chip with the rank read on the device (eig_wide.inc)
