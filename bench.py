@@ -641,6 +641,27 @@ def extras_cubes(ctx, line, xs, x, shape, n_vox, group_step, single_step, ms_per
         "read_frac": (4 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
         "read_write_frac": (8 * n_vox / (perm_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS}
     del dense
+    # ... and of a lockstep group in ONE launch (ndmps_encode_permute_many, what bf16 / fp64 storage and the DCT-free
+    # unfused paths run since round 4): per-volume launches of a 128^3 volume are mostly launch
+    ng = min(32, len(xs))
+    if ng > 1:
+        import ctypes as C
+
+        dense_g = torch.empty((ng, n_vox), dtype=torch.float32, device=device)
+        src_p = (C.c_void_p * ng)(*[v.data_ptr() for v in xs[:ng]])
+        dst_p = (C.c_void_p * ng)(*[d.data_ptr() for d in dense_g.unbind(0)])
+        _lib.check(lib.ndmps_encode_permute_many(plan.handle, ng, src_p, dst_p, 4, _lib.stream_ptr()))
+        e0.record()
+        for _ in range(5):
+            _lib.check(lib.ndmps_encode_permute_many(plan.handle, ng, src_p, dst_p, 4, _lib.stream_ptr()))
+        e1.record()
+        torch.cuda.synchronize()
+        grp_ms = e0.elapsed_time(e1) / 5
+        roofline["reshape_stage_group"] = {
+            "kernel": "encode_tiled_kernel<uint32, vec>, one launch for the group", "volumes": ng, "launch_us": grp_ms * 1e3,
+            "read_frac": (4 * ng * n_vox / (grp_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS,
+            "read_write_frac": (8 * ng * n_vox / (grp_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS}
+        del dense_g
 
     # one lockstep group of 8 on one stream (per-stage device times undisturbed by concurrent groups), a single volume
     n8 = min(8, len(xs))

@@ -37,11 +37,15 @@ SIGNATURES = {
     "ndmps_plan_emulate_reversed": (C.c_int, [C.c_int, p_i64, C.c_int, p_i64, C.c_int, p_i64]),
     "ndmps_encode_permute": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "ndmps_decode_permute": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "ndmps_encode_permute_many": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, vp]),
+    "ndmps_decode_permute_many": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, vp]),
     "ndmps_encode_permute_generic": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "ndmps_decode_permute_generic": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "ndmps_dct_basis_f32": (C.c_int, [vp, i64, vp]),
     "ndmps_dct_last_f32": (C.c_int, [vp, vp, i64, i64, vp, vp]),
     "ndmps_idct_last_f32": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ndmps_dct_last_many_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp), i64, i64, vp, vp]),
+    "ndmps_idct_last_many_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.POINTER(vp), i64, i64, vp, vp]),
     "ndmps_sumsq_f32": (C.c_int, [vp, i64, p_f64, vp, i64, vp]),
     "ndmps_minmax_f32": (C.c_int, [vp, i64, p_f32, p_f32, vp, i64, vp]),
     "ndmps_minmax_many_workspace_bytes": (i64, [C.c_int]),
@@ -50,6 +54,7 @@ SIGNATURES = {
     "ndmps_minmax_collect": (C.c_int, [C.c_int, vp, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]),
     "ndmps_minmax_many_f32": (C.c_int, [C.c_int, C.POINTER(vp), p_i64, p_f32, p_f64, vp, i64, vp]),
     "ndmps_scale_f32": (C.c_int, [vp, i64, C.c_double, vp]),
+    "ndmps_scale_many_f32": (C.c_int, [C.c_int, C.POINTER(vp), i64, p_f64, vp]),
     "ndmps_reduce_workspace_bytes": (i64, []),
     "ndmps_sgemm": (C.c_int, [C.c_int, C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp]),
     "ndmps_dgemm": (C.c_int, [C.c_int, C.c_int, i64, i64, i64, vp, i64, vp, i64, vp, i64, vp]),
@@ -205,6 +210,10 @@ def check(rc):
 def i64_array(values):
     arr = (C.c_int64 * len(values))(*[int(v) for v in values])
     return arr
+
+
+def f64_array(values):
+    return (C.c_double * len(values))(*[float(v) for v in values])
 
 
 def require_device():

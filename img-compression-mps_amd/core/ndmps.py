@@ -176,6 +176,11 @@ def _plan_for(shape, device_index, reverse_sites=False):
         return _PLAN_CACHE[key]
 
 
+def _ptr_array(tensors):
+    """Host array of the tensors' device pointers (the pointer tables of the library's group-wide launches)."""
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 def _dct_basis(n, device, f64=False):
     torch = _torch()
     key = (int(n), str(device), bool(f64))
@@ -482,25 +487,33 @@ class NDMPS:
                 # the norms of the whole group from ONE launch and one synchronisation (the reference divides volume by
                 # volume, ndmps.py:60-61; a sum-of-squares call per volume was a host round trip per volume)
                 _, sumsqs = _ft.minmax_many(xs, with_sumsq=True)
-                scale = lib.ndmps_scale_f64 if f64 else lib.ndmps_scale_f32
-                for x, ss in zip(xs, sumsqs):
-                    _lib.check(scale(x.data_ptr(), numel, 1.0 / float(np.sqrt(ss)), stream))
-            for x in xs:
-                if mode == "DCT":
-                    n = shape[-1]
-                    y = torch.empty_like(x)
-                    dct = lib.ndmps_dct_last_f64 if f64 else lib.ndmps_dct_last_f32
-                    _lib.check(dct(x.data_ptr(), y.data_ptr(), numel // n, n, _dct_basis(n, device, f64).data_ptr(), stream))
-                    x = y
-                x = x.to(store)
-                if gather is not None:
-                    denses.append(x)  # read in place by the fused sweep, never written
-                    continue
-                dense = torch.empty(numel, dtype=store, device=device)
+                if f64:
+                    for x, ss in zip(xs, sumsqs):
+                        _lib.check(lib.ndmps_scale_f64(x.data_ptr(), numel, 1.0 / float(np.sqrt(ss)), stream))
+                else:  # one launch for the group (the reference divides volume by volume, ndmps.py:60-61)
+                    _lib.check(lib.ndmps_scale_many_f32(batch, _ptr_array(xs), numel,
+                                                        _lib.f64_array([1.0 / float(np.sqrt(ss)) for ss in sumsqs]), stream))
+            if mode == "DCT":
+                n = shape[-1]
+                ys = list(torch.empty((batch,) + shape, dtype=xs[0].dtype, device=device).unbind(0))
+                if f64:
+                    for x, y in zip(xs, ys):
+                        _lib.check(lib.ndmps_dct_last_f64(x.data_ptr(), y.data_ptr(), numel // n, n,
+                                                          _dct_basis(n, device, True).data_ptr(), stream))
+                else:  # one launch for the group (ndmps.py:62-63 per volume)
+                    _lib.check(lib.ndmps_dct_last_many_f32(batch, _ptr_array(xs), _ptr_array(ys), numel // n, n,
+                                                           _dct_basis(n, device).data_ptr(), stream))
+                xs = ys
+            xs = [x.to(store) for x in xs]
+            if gather is not None:
+                denses = xs  # read in place by the fused sweep, never written
+            else:
+                # the reshape stage of the group in one launch (ndmps.py:66-71 per volume)
+                denses = list(torch.empty((batch, numel), dtype=store, device=device).unbind(0))
                 with _span("encode_permute"):
-                    _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), dense.data_ptr(), esize, stream))
-                denses.append(dense)
-            del xs, x
+                    _lib.check(lib.ndmps_encode_permute_many(plan.handle, batch, _ptr_array(xs), _ptr_array(denses), esize,
+                                                             stream))
+            del xs
 
             max_bonds = (C.c_int64 * (L + 1))()
             core_off = (C.c_int64 * (L + 1))()
@@ -566,15 +579,12 @@ class NDMPS:
                         n_tail, cws.data_ptr(), cws_bytes, stream))
                 recs = list(out.unbind(0))
                 if mode == "DCT":
+                    # the group's volumes sit back to back in `out`: their rows are the rows of one tall matrix
                     n_last = shape[-1]
-                    basis = _dct_basis(n_last, device)
-                    done = []
-                    for r in recs:
-                        rec = torch.empty_like(r)
-                        _lib.check(lib.ndmps_idct_last_f32(r.data_ptr(), rec.data_ptr(), numel // n_last, n_last,
-                                                           basis.data_ptr(), stream))
-                        done.append(rec)
-                    recs = done
+                    rec_all = torch.empty_like(out)
+                    _lib.check(lib.ndmps_idct_last_f32(out.data_ptr(), rec_all.data_ptr(), batch * (numel // n_last), n_last,
+                                                       _dct_basis(n_last, device).data_ptr(), stream))
+                    recs = list(rec_all.unbind(0))
                 del cws
             per_site = None
             if padded and bool((bonds_np == caps).all()) and not mirrored:
@@ -795,19 +805,47 @@ class NDMPS:
         if not objs:
             return []
         first = objs[0]
-        same = (len(objs) > 1 and first._shape is not None and first.mode in ("Std", "DCT")
-                and not os.environ.get("NDMPS_NO_FUSED_DECODE")
-                and all(o._shape == first._shape and o.mode == first.mode and o.mps.dtype == torch.float32
-                        and o.mps.device == first.mps.device and o.mps.dims == first.mps.dims for o in objs))
+        group = (len(objs) > 1 and first._shape is not None and first.mode in ("Std", "DCT")
+                 and all(o._shape == first._shape and o.mode == first.mode and o.mps.dtype == first.mps.dtype
+                         and o.mps.device == first.mps.device and o.mps.dims == first.mps.dims for o in objs))
+        same = group and first.mps.dtype == torch.float32 and not os.environ.get("NDMPS_NO_FUSED_DECODE")
         lib = _lib.load()
         n_tail = 0
         if same:
             dims_list = first.mps.dims
             cdims = _lib.i64_array(dims_list)
             n_tail = int(lib.ndmps_chain_tail_columns(len(dims_list), cdims))
-        if not same or n_tail <= 0:
+        if not group:
             return [o.to_tensor(as_torch=as_torch) for o in objs]
         device = first.mps.device
+        if not same or n_tail <= 0:
+            # bf16 / fp64 cores (or the fused decode switched off): a chain per volume, then the inverse permutation and
+            # the IDCT of the whole group in one launch each (to_tensor's steps, ndmps.py:140-153)
+            batch = len(objs)
+            with torch.cuda.device(device):
+                plan = _plan_for(first._shape, device.index or 0)
+                stream = _lib.stream_ptr()
+                with _span("chain"):
+                    denses = [o.mps.to_dense() for o in objs]
+                out = torch.empty((batch,) + tuple(first._shape), dtype=denses[0].dtype, device=device)
+                with _span("decode_permute"):
+                    _lib.check(lib.ndmps_decode_permute_many(plan.handle, batch, _ptr_array(denses),
+                                                             _ptr_array(list(out.unbind(0))), denses[0].element_size(), stream))
+                del denses
+                if first.mode == "DCT":
+                    n = first._shape[-1]
+                    f64 = out.dtype == torch.float64
+                    if not f64:
+                        out = out.to(torch.float32)  # the IDCT kernel is fp32 (bf16 storage: upcast copy)
+                    rec_all = torch.empty_like(out)
+                    idct = lib.ndmps_idct_last_f64 if f64 else lib.ndmps_idct_last_f32
+                    _lib.check(idct(out.data_ptr(), rec_all.data_ptr(), batch * (plan.numel // n), n,
+                                    _dct_basis(n, device, f64).data_ptr(), stream))
+                    out = rec_all
+                recs = list(out.unbind(0))
+            if as_torch:
+                return recs
+            return [(r if r.dtype == torch.float64 else r.to(torch.float32)).cpu().numpy() for r in recs]
         batch, L = len(objs), len(dims_list)
         with torch.cuda.device(device):
             plan = _plan_for(first._shape, device.index or 0)
@@ -830,15 +868,12 @@ class NDMPS:
                     n_tail, ws.data_ptr(), ws_bytes, stream))
             recs = list(out.unbind(0))
             if first.mode == "DCT":
+                # the volumes sit back to back in `out`: their rows are the rows of one tall matrix, one launch
                 n = first._shape[-1]
-                basis = _dct_basis(n, device)
-                done = []
-                for r in recs:
-                    rec = torch.empty_like(r)
-                    _lib.check(lib.ndmps_idct_last_f32(r.data_ptr(), rec.data_ptr(), plan.numel // n, n,
-                                                       basis.data_ptr(), stream))
-                    done.append(rec)
-                recs = done
+                rec_all = torch.empty_like(out)
+                _lib.check(lib.ndmps_idct_last_f32(out.data_ptr(), rec_all.data_ptr(), batch * (plan.numel // n), n,
+                                                   _dct_basis(n, device).data_ptr(), stream))
+                recs = list(rec_all.unbind(0))
         if as_torch:
             return recs
         return [r.cpu().numpy() for r in recs]

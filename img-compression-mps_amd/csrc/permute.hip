@@ -67,9 +67,19 @@ struct ndmps_plan {
 
 namespace {
 
+// The volumes of one launch (a lockstep group goes in chunks of kPermVols): pointers as kernel arguments.  The tiled
+// kernels run over (volume, tile) pairs -- at 128^3 a volume is 8 us of launch around 2 us of traffic --, the generic
+// ones take the volume from blockIdx.y.
+constexpr int kPermVols = 32;
+struct PermVols {
+  const void* in[kPermVols];
+  void* out[kPermVols];
+};
+
 template <typename T>
-__global__ void __launch_bounds__(256) encode_generic_kernel(DevPlan p, const T* __restrict__ src,
-                                                              T* __restrict__ dst) {
+__global__ void __launch_bounds__(256) encode_generic_kernel(DevPlan p, PermVols pv) {
+  const T* __restrict__ src = static_cast<const T*>(pv.in[blockIdx.y]);
+  T* __restrict__ dst = static_cast<T*>(pv.out[blockIdx.y]);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < p.numel; o += stride) {
     int64_t rem = o, off = 0;
@@ -84,8 +94,9 @@ __global__ void __launch_bounds__(256) encode_generic_kernel(DevPlan p, const T*
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) decode_generic_kernel(DevPlan p, const T* __restrict__ dense,
-                                                              T* __restrict__ out) {
+__global__ void __launch_bounds__(256) decode_generic_kernel(DevPlan p, PermVols pv) {
+  const T* __restrict__ dense = static_cast<const T*>(pv.in[blockIdx.y]);
+  T* __restrict__ out = static_cast<T*>(pv.out[blockIdx.y]);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < p.numel; f += stride) {
     int64_t rem = f, off = 0;
@@ -119,9 +130,9 @@ struct Vec4 {
 // VEC: every sorted run of source offsets is a multiple of 4 elements and 4-aligned, so both sides
 // move 4 elements per lane (16 B for fp32) through a packed per-group table (12 B per 4 elements,
 // L1/L2-resident).
+// n_tiles: tiles of ONE volume; the launch covers n_total = volumes x n_tiles of them
 template <typename T, bool VEC>
-__global__ void __launch_bounds__(256) encode_tiled_kernel(DevPlan p, const T* __restrict__ src,
-                                                           T* __restrict__ dst, int64_t n_tiles) {
+__global__ void __launch_bounds__(256) encode_tiled_kernel(DevPlan p, PermVols pv, int64_t n_tiles, int64_t n_total) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   const int tile = (int)p.tile;
@@ -134,7 +145,8 @@ __global__ void __launch_bounds__(256) encode_tiled_kernel(DevPlan p, const T* _
     const int n_groups = tile / 4;
     Vec4<T> x[kGroups];
     auto gather = [&](int64_t t) {
-      const T* s = src + tile_source_base(p, t);
+      const int64_t vol = t / n_tiles;
+      const T* s = static_cast<const T*>(pv.in[vol]) + tile_source_base(p, t - vol * n_tiles);
 #pragma unroll
       for (int u = 0; u < kGroups; ++u) {
         const int g = threadIdx.x + u * 256;
@@ -142,8 +154,8 @@ __global__ void __launch_bounds__(256) encode_tiled_kernel(DevPlan p, const T* _
       }
     };
     int64_t t = blockIdx.x;
-    if (t < n_tiles) gather(t);
-    for (; t < n_tiles; t += gridDim.x) {
+    if (t < n_total) gather(t);
+    for (; t < n_total; t += gridDim.x) {
 #pragma unroll
       for (int u = 0; u < kGroups; ++u) {
         const int g = threadIdx.x + u * 256;
@@ -156,33 +168,35 @@ __global__ void __launch_bounds__(256) encode_tiled_kernel(DevPlan p, const T* _
         }
       }
       __syncthreads();
-      if (t + gridDim.x < n_tiles) gather(t + gridDim.x);  // flies under the stores below
-      T* d = dst + t * tile;
+      if (t + gridDim.x < n_total) gather(t + gridDim.x);  // flies under the stores below
+      const int64_t vol = t / n_tiles;
+      T* d = static_cast<T*>(pv.out[vol]) + (t - vol * n_tiles) * tile;
       for (int k = threadIdx.x * 4; k < tile; k += 1024)
         *reinterpret_cast<Vec4<T>*>(d + k) = *reinterpret_cast<const Vec4<T>*>(lds + k);
       __syncthreads();
     }
     return;
   }
-  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const T* s = src + tile_source_base(p, t);
+  for (int64_t t = blockIdx.x; t < n_total; t += gridDim.x) {
+    const int64_t vol = t / n_tiles, tl = t - vol * n_tiles;
+    const T* s = static_cast<const T*>(pv.in[vol]) + tile_source_base(p, tl);
     for (int k = threadIdx.x; k < tile; k += 256) lds[p.order[k]] = s[p.src_sorted[k]];
     __syncthreads();
-    T* d = dst + t * tile;
+    T* d = static_cast<T*>(pv.out[vol]) + tl * tile;
     for (int k = threadIdx.x; k < tile; k += 256) d[k] = lds[k];
     __syncthreads();
   }
 }
 
 template <typename T, bool VEC>
-__global__ void __launch_bounds__(256) decode_tiled_kernel(DevPlan p, const T* __restrict__ dense,
-                                                           T* __restrict__ out, int64_t n_tiles) {
+__global__ void __launch_bounds__(256) decode_tiled_kernel(DevPlan p, PermVols pv, int64_t n_tiles, int64_t n_total) {
   extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   const int tile = (int)p.tile;
   const uint32_t* __restrict__ tab = p.vec_tab;
-  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const T* d = dense + t * tile;
+  for (int64_t t = blockIdx.x; t < n_total; t += gridDim.x) {
+    const int64_t vol = t / n_tiles, tl = t - vol * n_tiles;
+    const T* d = static_cast<const T*>(pv.in[vol]) + tl * tile;
     if (VEC) {
       for (int k = threadIdx.x * 4; k < tile; k += 1024)
         *reinterpret_cast<Vec4<T>*>(lds + k) = *reinterpret_cast<const Vec4<T>*>(d + k);
@@ -190,7 +204,7 @@ __global__ void __launch_bounds__(256) decode_tiled_kernel(DevPlan p, const T* _
       for (int k = threadIdx.x; k < tile; k += 256) lds[k] = d[k];
     }
     __syncthreads();
-    T* o = out + tile_source_base(p, t);
+    T* o = static_cast<T*>(pv.out[vol]) + tile_source_base(p, tl);
     if (VEC) {
       for (int g = threadIdx.x; g < tile / 4; g += 256) {
         const uint32_t off = tab[3 * g], o01 = tab[3 * g + 1], o23 = tab[3 * g + 2];
@@ -421,52 +435,61 @@ int grid_for(int64_t work_items, int per_block) {
 }
 
 template <typename T>
-int launch(const ndmps_plan* plan, const void* in, void* out, bool encode, bool force_generic,
+int launch(const ndmps_plan* plan, int count, const void* const* in, void* const* out, bool encode, bool force_generic,
            hipStream_t stream) {
   const DevPlan& dp = plan->dev;
-  if (plan->tiled && !force_generic) {
-    const int64_t n_tiles = dp.numel / dp.tile;
-    // 4-wide accesses also need 4-element-aligned buffers (torch allocations are 256-B aligned)
-    const bool vec = dp.vec4 && ((uintptr_t)in % (4 * sizeof(T)) == 0) && ((uintptr_t)out % (4 * sizeof(T)) == 0);
-    const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ndmps::kNumCU * 8);
-    const size_t lds = (size_t)dp.tile * sizeof(T);
-    if (encode) {
-      if (vec) hipLaunchKernelGGL((encode_tiled_kernel<T, true>), dim3(grid), dim3(256), lds, stream, dp,
-                                  (const T*)in, (T*)out, n_tiles);
-      else hipLaunchKernelGGL((encode_tiled_kernel<T, false>), dim3(grid), dim3(256), lds, stream, dp,
-                              (const T*)in, (T*)out, n_tiles);
-    } else {
-      if (vec) hipLaunchKernelGGL((decode_tiled_kernel<T, true>), dim3(grid), dim3(256), lds, stream, dp,
-                                  (const T*)in, (T*)out, n_tiles);
-      else hipLaunchKernelGGL((decode_tiled_kernel<T, false>), dim3(grid), dim3(256), lds, stream, dp,
-                              (const T*)in, (T*)out, n_tiles);
+  for (int v0 = 0; v0 < count; v0 += kPermVols) {
+    const int nv = std::min(kPermVols, count - v0);
+    PermVols pv;
+    bool aligned = true;
+    for (int v = 0; v < kPermVols; ++v) {
+      pv.in[v] = v < nv ? in[v0 + v] : nullptr;
+      pv.out[v] = v < nv ? out[v0 + v] : nullptr;
+      if (v < nv)  // 4-wide accesses also need 4-element-aligned buffers (torch allocations are 256-B aligned)
+        aligned = aligned && ((uintptr_t)pv.in[v] % (4 * sizeof(T)) == 0) && ((uintptr_t)pv.out[v] % (4 * sizeof(T)) == 0);
     }
-  } else {
-    const int grid = grid_for(dp.numel, 256);
-    if (encode)
-      hipLaunchKernelGGL(encode_generic_kernel<T>, dim3(grid), dim3(256), 0, stream, dp, (const T*)in,
-                         (T*)out);
-    else
-      hipLaunchKernelGGL(decode_generic_kernel<T>, dim3(grid), dim3(256), 0, stream, dp, (const T*)in,
-                         (T*)out);
+    if (plan->tiled && !force_generic) {
+      const int64_t n_tiles = dp.numel / dp.tile, n_total = n_tiles * nv;
+      const bool vec = dp.vec4 && aligned;
+      const int grid = (int)std::min<int64_t>(n_total, (int64_t)ndmps::kNumCU * 8);
+      const size_t lds = (size_t)dp.tile * sizeof(T);
+      if (encode) {
+        if (vec) hipLaunchKernelGGL((encode_tiled_kernel<T, true>), dim3(grid), dim3(256), lds, stream, dp, pv, n_tiles, n_total);
+        else hipLaunchKernelGGL((encode_tiled_kernel<T, false>), dim3(grid), dim3(256), lds, stream, dp, pv, n_tiles, n_total);
+      } else {
+        if (vec) hipLaunchKernelGGL((decode_tiled_kernel<T, true>), dim3(grid), dim3(256), lds, stream, dp, pv, n_tiles, n_total);
+        else hipLaunchKernelGGL((decode_tiled_kernel<T, false>), dim3(grid), dim3(256), lds, stream, dp, pv, n_tiles, n_total);
+      }
+    } else {
+      const dim3 grid((unsigned)grid_for(dp.numel, 256), (unsigned)nv);
+      if (encode) hipLaunchKernelGGL(encode_generic_kernel<T>, grid, dim3(256), 0, stream, dp, pv);
+      else hipLaunchKernelGGL(decode_generic_kernel<T>, grid, dim3(256), 0, stream, dp, pv);
+    }
   }
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }
 
-int dispatch(const ndmps_plan* plan, const void* in, void* out, int elem_bytes, bool encode,
-             bool force_generic, ndmps_stream_t stream) {
+int dispatch_many(const ndmps_plan* plan, int count, const void* const* in, void* const* out, int elem_bytes, bool encode,
+                  bool force_generic, ndmps_stream_t stream) {
   NDMPS_REQUIRE(plan != nullptr, "plan is NULL");
-  NDMPS_REQUIRE(in != nullptr && out != nullptr && in != out, "permute needs distinct non-NULL buffers");
+  NDMPS_REQUIRE(count >= 1 && in != nullptr && out != nullptr, "permute needs at least one volume and its pointer tables");
+  for (int v = 0; v < count; ++v)
+    NDMPS_REQUIRE(in[v] != nullptr && out[v] != nullptr && in[v] != out[v], "permute needs distinct non-NULL buffers (volume %d)", v);
   hipStream_t s = (hipStream_t)stream;
   switch (elem_bytes) {
-    case 2: return launch<uint16_t>(plan, in, out, encode, force_generic, s);
-    case 4: return launch<uint32_t>(plan, in, out, encode, force_generic, s);
-    case 8: return launch<uint64_t>(plan, in, out, encode, force_generic, s);
+    case 2: return launch<uint16_t>(plan, count, in, out, encode, force_generic, s);
+    case 4: return launch<uint32_t>(plan, count, in, out, encode, force_generic, s);
+    case 8: return launch<uint64_t>(plan, count, in, out, encode, force_generic, s);
     default:
       ndmps::set_error("elem_bytes=%d not supported (2, 4 or 8)", elem_bytes);
       return NDMPS_EINVAL;
   }
+}
+
+int dispatch(const ndmps_plan* plan, const void* in, void* out, int elem_bytes, bool encode,
+             bool force_generic, ndmps_stream_t stream) {
+  return dispatch_many(plan, 1, &in, &out, elem_bytes, encode, force_generic, stream);
 }
 
 }  // namespace
@@ -624,4 +647,16 @@ extern "C" int ndmps_encode_permute_generic(const ndmps_plan_t* plan, const void
 extern "C" int ndmps_decode_permute_generic(const ndmps_plan_t* plan, const void* d_dense, void* d_out,
                                             int elem_bytes, ndmps_stream_t stream) {
   return dispatch(plan, d_dense, d_out, elem_bytes, false, true, stream);
+}
+
+// One launch for the volumes of a lockstep group (chunks of 32): h_src / h_dst are HOST arrays of `count` device pointers.
+// What the reference does volume by volume in a Python loop (evaluation/benchmark.py:80-100 around core/ndmps.py:66-71
+// and :144-147); bit-exact like the single-volume calls.
+extern "C" int ndmps_encode_permute_many(const ndmps_plan_t* plan, int count, const void* const* h_src, void* const* h_dst,
+                                         int elem_bytes, ndmps_stream_t stream) {
+  return dispatch_many(plan, count, h_src, h_dst, elem_bytes, true, false, stream);
+}
+extern "C" int ndmps_decode_permute_many(const ndmps_plan_t* plan, int count, const void* const* h_dense, void* const* h_out,
+                                         int elem_bytes, ndmps_stream_t stream) {
+  return dispatch_many(plan, count, h_dense, h_out, elem_bytes, false, false, stream);
 }

@@ -277,9 +277,15 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // NN: the transform length as a compile-time constant (0: taken from the argument): stage count, strides and loop trip
 // counts fold into the instruction stream -- the kernel is bound by the instructions a wave issues per row, not by LDS
 // or HBM bandwidth (262144 rows of 512 in 378 us = 2.7 rows per us and CU against ~600 VALU instructions per row)
+// The volumes of one launch (a lockstep group goes in chunks of kDctVols): `rows` counts the rows of all of them, row r
+// belongs to volume r / rows_per_vol.
+constexpr int kDctVols = 32;
+struct DctVols {
+  const float* in[kDctVols];
+  float* out[kDctVols];
+};
 template <bool INVERSE, int NN>
-__global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows,
-                                                      int N_arg) {
+__global__ void __launch_bounds__(256) dct_fft_kernel(DctVols dv, int64_t rows, int64_t rows_per_vol, int N_arg) {
   extern __shared__ __attribute__((aligned(16))) float fft_lds[];
   const int N = NN ? NN : N_arg;
   const int M = N / 2;
@@ -312,11 +318,13 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
   float4 nx[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
                   make_float4(0.f, 0.f, 0.f, 0.f)};
   auto fetch_row = [&](int64_t row) {
-    const float4* in4 = reinterpret_cast<const float4*>(src + row * N);
+    if (row >= rows) return;  // wave-uniform
+    const int64_t vol = row / rows_per_vol;
+    const float4* in4 = reinterpret_cast<const float4*>(dv.in[vol] + (row - vol * rows_per_vol) * N);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int i = lane + 64 * t;
-      if (i < N / 4 && row < rows) nx[t] = in4[i];
+      if (i < N / 4) nx[t] = in4[i];
     }
   };
   fetch_row((int64_t)blockIdx.x * 4 + wave);
@@ -438,7 +446,7 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
       // x[4i .. 4i + 3] = (v[2i], v[N - 1 - 2i], v[2i + 1], v[N - 2 - 2i]) = (Re z[i], Im z[M-1-i], Im z[i], Re z[M-1-i]):
       // straight from the last stage's buffer to a coalesced 16-byte store
       const float inv = 1.0f / (float)M;
-      float4* out4 = reinterpret_cast<float4*>(dst + row * N);
+      float4* out4 = reinterpret_cast<float4*>(dv.out[row / rows_per_vol] + (row % rows_per_vol) * N);
 #pragma unroll
       for (int i = lane; i < N / 4; i += 64) {
         const Cf zi = a[i], zj = a[M - 1 - i];
@@ -446,7 +454,7 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
       }
     } else {
       wave_lds_sync();
-      float4* out4 = reinterpret_cast<float4*>(dst + row * N);
+      float4* out4 = reinterpret_cast<float4*>(dv.out[row / rows_per_vol] + (row % rows_per_vol) * N);
       const float4* rb4 = reinterpret_cast<const float4*>(rowbuf);
 #pragma unroll
       for (int i = lane; i < N / 4; i += 64) out4[i] = rb4[i];
@@ -455,12 +463,13 @@ __global__ void __launch_bounds__(256) dct_fft_kernel(const float* __restrict__ 
   }
 }
 
-inline bool dct_fft_ok(int64_t rows, int64_t n, const void* a, const void* b) {
+inline bool dct_fft_ok(int64_t rows, int64_t n, const void* a, const void* b) {  // one volume's operands
   return n >= 64 && n <= 1024 && (n & (n - 1)) == 0 && rows >= 1 && (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0 &&
          !getenv("NDMPS_DCT_GEMM");
 }
 template <bool INVERSE, int NN>
-int dct_fft_launch_n(const float* src, float* dst, int64_t rows, int64_t n, hipStream_t s) {
+int dct_fft_launch_n(const DctVols& dv, int count, int64_t rows_per_vol, int64_t n, hipStream_t s) {
+  const int64_t rows = rows_per_vol * count;
   const int M = (int)n / 2;
   const size_t lds = (size_t)(M + 2 * (M + 1)) * sizeof(Cf) + (size_t)4 * (n + 4 * M) * sizeof(float);
   // exactly the workgroups the device keeps resident at once (every workgroup loops over rows: a partly filled second
@@ -481,18 +490,65 @@ int dct_fft_launch_n(const float* src, float* dst, int64_t rows, int64_t n, hipS
     }
   }
   const int grid = (int)std::min<int64_t>((rows + 3) / 4, (int64_t)ndmps::kNumCU * std::max(per_cu, 1));
-  hipLaunchKernelGGL((dct_fft_kernel<INVERSE, NN>), dim3(grid), dim3(256), lds, s, src, dst, rows, (int)n);
+  hipLaunchKernelGGL((dct_fft_kernel<INVERSE, NN>), dim3(grid), dim3(256), lds, s, dv, rows, rows_per_vol, (int)n);
   NDMPS_LAUNCH_CHECK();
   return NDMPS_OK;
 }
 template <bool INVERSE>
-int dct_fft_launch(const float* src, float* dst, int64_t rows, int64_t n, hipStream_t s) {
+int dct_fft_launch_vols(const DctVols& dv, int count, int64_t rows_per_vol, int64_t n, hipStream_t s) {
   switch (n) {  // the volume edges that occur: constants; anything else: the generic kernel
-    case 128: return dct_fft_launch_n<INVERSE, 128>(src, dst, rows, n, s);
-    case 256: return dct_fft_launch_n<INVERSE, 256>(src, dst, rows, n, s);
-    case 512: return dct_fft_launch_n<INVERSE, 512>(src, dst, rows, n, s);
-    default: return dct_fft_launch_n<INVERSE, 0>(src, dst, rows, n, s);
+    case 128: return dct_fft_launch_n<INVERSE, 128>(dv, count, rows_per_vol, n, s);
+    case 256: return dct_fft_launch_n<INVERSE, 256>(dv, count, rows_per_vol, n, s);
+    case 512: return dct_fft_launch_n<INVERSE, 512>(dv, count, rows_per_vol, n, s);
+    default: return dct_fft_launch_n<INVERSE, 0>(dv, count, rows_per_vol, n, s);
   }
+}
+template <bool INVERSE>
+int dct_fft_launch(const float* src, float* dst, int64_t rows, int64_t n, hipStream_t s) {
+  DctVols dv = {};
+  dv.in[0] = src;
+  dv.out[0] = dst;
+  return dct_fft_launch_vols<INVERSE>(dv, 1, rows, n, s);
+}
+// the volumes of a lockstep group, thirty-two per launch; volumes the FFT does not take (row length, alignment) and
+// every volume when the row length is not a power of two go through the basis product one by one
+template <bool INVERSE>
+int dct_many(int count, const float* const* h_in, float* const* h_out, int64_t rows, int64_t n, const float* d_basis,
+             hipStream_t s) {
+  bool fft = true;
+  for (int v = 0; v < count; ++v) {
+    NDMPS_REQUIRE(h_in[v] && h_out[v] && h_in[v] != h_out[v], "the DCT is out of place (volume %d)", v);
+    fft = fft && dct_fft_ok(rows, n, h_in[v], h_out[v]);
+  }
+  if (!fft) {
+    NDMPS_REQUIRE(d_basis != nullptr, "this row length needs the DCT basis");
+    for (int v = 0; v < count; ++v)
+      NDMPS_TRY(ndmps_sgemm(0, INVERSE ? 1 : 0, rows, n, n, h_in[v], n, d_basis, n, h_out[v], n, (ndmps_stream_t)s));
+    return NDMPS_OK;
+  }
+  for (int v0 = 0; v0 < count; v0 += kDctVols) {
+    const int nv = std::min(kDctVols, count - v0);
+    DctVols dv = {};
+    for (int v = 0; v < nv; ++v) {
+      dv.in[v] = h_in[v0 + v];
+      dv.out[v] = h_out[v0 + v];
+    }
+    NDMPS_TRY(dct_fft_launch_vols<INVERSE>(dv, nv, rows, n, s));
+  }
+  return NDMPS_OK;
+}
+
+// x[t] *= factor[t] for the tensors of a lockstep group in one launch (blockIdx.y = tensor)
+constexpr int kScaleVols = 32;
+struct ScaleVols {
+  float* x[kScaleVols];
+  double factor[kScaleVols];
+};
+__global__ void __launch_bounds__(256) scale_many_kernel(ScaleVols sv, int64_t n) {
+  float* __restrict__ x = sv.x[blockIdx.y];
+  const double f = sv.factor[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] = (float)((double)x[i] * f);
 }
 
 int stream_grid(int64_t n) {
@@ -772,6 +828,40 @@ extern "C" int ndmps_idct_last_f32(const float* d_y, float* d_x, int64_t rows, i
   NDMPS_REQUIRE(d_x != d_y, "IDCT is out of place");
   if (d_x && d_y && dct_fft_ok(rows, n, d_x, d_y)) return dct_fft_launch<true>(d_y, d_x, rows, n, (hipStream_t)stream);
   return ndmps_sgemm(0, 1, rows, n, n, d_y, n, d_basis, n, d_x, n, stream);
+}
+
+// The same transforms for the volumes of a lockstep group in one launch (thirty-two per launch): h_x / h_y are HOST arrays
+// of `count` device pointers, every volume (rows, n) row-major.  The reference transforms volume by volume in a Python
+// loop (evaluation/benchmark.py:80-100 around core/ndmps.py:62-63 and :152-153); results equal the single-volume calls
+// bit for bit.
+extern "C" int ndmps_dct_last_many_f32(int count, const float* const* h_x, float* const* h_y, int64_t rows, int64_t n,
+                                       const float* d_basis, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(count >= 1 && h_x && h_y && rows >= 1 && n >= 1, "bad dct_last_many argument");
+  return dct_many<false>(count, h_x, h_y, rows, n, d_basis, (hipStream_t)stream);
+}
+extern "C" int ndmps_idct_last_many_f32(int count, const float* const* h_y, float* const* h_x, int64_t rows, int64_t n,
+                                        const float* d_basis, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(count >= 1 && h_x && h_y && rows >= 1 && n >= 1, "bad idct_last_many argument");
+  return dct_many<true>(count, h_y, h_x, rows, n, d_basis, (hipStream_t)stream);
+}
+// h_x[t][0 .. n) *= h_factor[t] for `count` fp32 tensors of n elements each, thirty-two per launch (the division by the
+// norm of core/ndmps.py:60-61 for a whole lockstep group)
+extern "C" int ndmps_scale_many_f32(int count, float* const* h_x, int64_t n, const double* h_factor, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(count >= 1 && h_x && h_factor && n >= 0, "bad scale_many argument");
+  if (n == 0) return NDMPS_OK;
+  for (int v0 = 0; v0 < count; v0 += kScaleVols) {
+    const int nv = std::min(kScaleVols, count - v0);
+    ScaleVols sv = {};
+    for (int v = 0; v < nv; ++v) {
+      NDMPS_REQUIRE(h_x[v0 + v] != nullptr, "tensor %d is NULL", v0 + v);
+      sv.x[v] = h_x[v0 + v];
+      sv.factor[v] = h_factor[v0 + v];
+    }
+    const int gx = (int)std::min<int64_t>(std::max<int64_t>(ndmps::ceil_div(n, 256 * 8), 1), (int64_t)ndmps::kNumCU * 8);
+    hipLaunchKernelGGL(scale_many_kernel, dim3(gx, nv), dim3(256), 0, (hipStream_t)stream, sv, n);
+  }
+  NDMPS_LAUNCH_CHECK();
+  return NDMPS_OK;
 }
 
 extern "C" int ndmps_quantize_f32(const float* d_x, int64_t n, float lo, float hi, int bits, void* d_q,

@@ -96,6 +96,13 @@ int ndmps_encode_permute(const ndmps_plan_t* plan, const void* d_src, void* d_ds
 /* out (C-order over shape) <- dense (C-order over site dims); bit-exact */
 int ndmps_decode_permute(const ndmps_plan_t* plan, const void* d_dense, void* d_out,
                          int elem_bytes, ndmps_stream_t stream);
+/* The same permutations for the volumes of a lockstep group in ONE launch (thirty-two per launch): h_src / h_dst are
+ * HOST arrays of `count` device pointers.  Replaces the per-volume Python loop around core/ndmps.py:66-71 and :144-147
+ * (evaluation/benchmark.py:80-100); bit-exact like the single-volume calls. */
+int ndmps_encode_permute_many(const ndmps_plan_t* plan, int count, const void* const* h_src, void* const* h_dst,
+                              int elem_bytes, ndmps_stream_t stream);
+int ndmps_decode_permute_many(const ndmps_plan_t* plan, int count, const void* const* h_dense, void* const* h_out,
+                              int elem_bytes, ndmps_stream_t stream);
 /* force the generic gather kernels (testing / A-B timing) */
 int ndmps_encode_permute_generic(const ndmps_plan_t* plan, const void* d_src, void* d_dst,
                                  int elem_bytes, ndmps_stream_t stream);
@@ -113,6 +120,14 @@ int ndmps_dct_last_f32(const float* d_x, float* d_y, int64_t rows, int64_t n,
                        const float* d_basis, ndmps_stream_t stream);
 int ndmps_idct_last_f32(const float* d_y, float* d_x, int64_t rows, int64_t n,
                         const float* d_basis, ndmps_stream_t stream);
+/* The same transforms for the volumes of a lockstep group in ONE launch (thirty-two per launch): h_x / h_y are HOST
+ * arrays of `count` device pointers, every volume (rows, n) row-major and distinct from its result.  Replaces the
+ * per-volume Python loop around core/ndmps.py:62-63 and :152-153 (evaluation/benchmark.py:80-100); results equal the
+ * single-volume calls bit for bit.  d_basis may be NULL when n is a power of two in [64, 1024] (the FFT route). */
+int ndmps_dct_last_many_f32(int count, const float* const* h_x, float* const* h_y, int64_t rows, int64_t n,
+                            const float* d_basis, ndmps_stream_t stream);
+int ndmps_idct_last_many_f32(int count, const float* const* h_y, float* const* h_x, int64_t rows, int64_t n,
+                             const float* d_basis, ndmps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Reductions that keep NDMPS state (core/ndmps.py:60-61 norm, :75,:80-82 boundary_list).
@@ -141,6 +156,9 @@ int ndmps_minmax_arena_launch_f32(const float* d_base, int64_t row_stride, int b
                                   ndmps_stream_t stream);
 int ndmps_minmax_collect(int count, const double* d_partial, float* h_out, double* h_sumsq, ndmps_stream_t stream);
 int ndmps_scale_f32(float* d_x, int64_t n, double factor, ndmps_stream_t stream);
+/* h_x[t][0 .. n) *= h_factor[t] for `count` fp32 tensors of n elements each in one launch per thirty-two tensors: the
+ * division by the norm of core/ndmps.py:60-61 for a whole lockstep group (h_x, h_factor: HOST arrays). */
+int ndmps_scale_many_f32(int count, float* const* h_x, int64_t n, const double* h_factor, ndmps_stream_t stream);
 int64_t ndmps_reduce_workspace_bytes(void);
 
 /* ---------------------------------------------------------------------------------

@@ -85,6 +85,72 @@ def test_permute_bit_exact(shape):
             assert np.array_equal(back.cpu().numpy().view(src.dtype), src), (shape, dtype)
 
 
+def _ptrs(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+@pytest.mark.parametrize("shape,count", [((128, 128, 128), 5), ((16, 16, 16), 40), ((30, 40, 50), 3), ((7, 12), 33),
+                                         ((12, 8, 20, 6), 2)], ids=str)
+def test_permute_of_a_group_in_one_launch_is_bit_exact(shape, count):
+    """ndmps_encode_permute_many / ndmps_decode_permute_many (one launch per thirty-two volumes, tiled and generic plans,
+    2 / 4 / 8-byte elements) against the single-volume calls, bit for bit, on separately allocated volumes."""
+    lib = _lib.load()
+    n = int(np.prod(shape))
+    plan = _plan_for(shape, 0)
+    gen = torch.Generator(device=DEV).manual_seed(n + count)
+    for dt, nbytes in ((torch.int16, 2), (torch.float32, 4), (torch.float64, 8)):
+        if dt == torch.int16:
+            srcs = [torch.randint(-32768, 32767, (n,), dtype=dt, device=DEV, generator=gen) for _ in range(count)]
+        else:
+            srcs = [torch.randn(n, dtype=dt, device=DEV, generator=gen) for _ in range(count)]
+        one = [torch.zeros_like(x) for x in srcs]
+        for x, d in zip(srcs, one):
+            _lib.check(lib.ndmps_encode_permute(plan.handle, x.data_ptr(), d.data_ptr(), nbytes, sp()))
+        many = list(torch.zeros((count, n), dtype=dt, device=DEV).unbind(0))
+        _lib.check(lib.ndmps_encode_permute_many(plan.handle, count, _ptrs(srcs), _ptrs(many), nbytes, sp()))
+        assert all(torch.equal(a, b) for a, b in zip(one, many)), (shape, dt)
+        back = [torch.zeros_like(x) for x in srcs]
+        _lib.check(lib.ndmps_decode_permute_many(plan.handle, count, _ptrs(many), _ptrs(back), nbytes, sp()))
+        assert all(torch.equal(a, b) for a, b in zip(srcs, back)), (shape, dt)
+    with pytest.raises(ValueError):  # a volume permuted onto itself
+        _lib.check(lib.ndmps_encode_permute_many(plan.handle, 2, _ptrs(srcs[:2]), _ptrs([many[0], srcs[1]]), 8, sp()))
+
+
+@pytest.mark.parametrize("rows,n,count", [(64, 128, 3), (37, 512, 35), (9, 96, 4), (1001, 256, 2)])
+def test_dct_and_scaling_of_a_group_in_one_launch(rows, n, count):
+    """ndmps_dct_last_many_f32 / ndmps_idct_last_many_f32 / ndmps_scale_many_f32 against the single-volume calls, bit for
+    bit (FFT route in chunks of thirty-two volumes, basis product for other row lengths)."""
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(rows * n + count)
+    xs = [torch.rand((rows, n), dtype=torch.float32, device=DEV, generator=gen) for _ in range(count)]
+    basis = torch.empty((n, n), dtype=torch.float32, device=DEV)
+    _lib.check(lib.ndmps_dct_basis_f32(basis.data_ptr(), n, sp()))
+    one = [torch.empty_like(x) for x in xs]
+    for x, y in zip(xs, one):
+        _lib.check(lib.ndmps_dct_last_f32(x.data_ptr(), y.data_ptr(), rows, n, basis.data_ptr(), sp()))
+    many = list(torch.empty((count, rows, n), dtype=torch.float32, device=DEV).unbind(0))
+    _lib.check(lib.ndmps_dct_last_many_f32(count, _ptrs(xs), _ptrs(many), rows, n, basis.data_ptr(), sp()))
+    assert all(torch.equal(a, b) for a, b in zip(one, many))
+    back_one = [torch.empty_like(x) for x in xs]
+    for y, x in zip(one, back_one):
+        _lib.check(lib.ndmps_idct_last_f32(y.data_ptr(), x.data_ptr(), rows, n, basis.data_ptr(), sp()))
+    back_many = [torch.empty_like(x) for x in xs]
+    _lib.check(lib.ndmps_idct_last_many_f32(count, _ptrs(many), _ptrs(back_many), rows, n, basis.data_ptr(), sp()))
+    assert all(torch.equal(a, b) for a, b in zip(back_one, back_many))
+    assert max(float((a - b).abs().max()) for a, b in zip(xs, back_many)) <= 3e-6
+    # a stacked group is one tall matrix for the single call: the same bits again
+    tall = torch.empty((count, rows, n), dtype=torch.float32, device=DEV)
+    _lib.check(lib.ndmps_idct_last_f32(torch.stack(one).data_ptr(), tall.data_ptr(), count * rows, n, basis.data_ptr(), sp()))
+    assert all(torch.equal(a, b) for a, b in zip(back_one, tall.unbind(0)))
+    factors = [1.0 / (1.5 + i) for i in range(count)]
+    want = [x.clone() for x in xs]
+    for x, f in zip(want, factors):
+        _lib.check(lib.ndmps_scale_f32(x.data_ptr(), rows * n, f, sp()))
+    got = [x.clone() for x in xs]
+    _lib.check(lib.ndmps_scale_many_f32(count, _ptrs(got), rows * n, _lib.f64_array(factors), sp()))
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+
+
 def test_permute_rejects_bad_arguments():
     lib = _lib.load()
     plan = _plan_for((8, 8), 0)
@@ -1082,6 +1148,33 @@ def test_fused_decode_is_bit_identical_to_chain_plus_permute(shape, chi):
     assert torch.equal(fused, unfused)
     n_tail = lib.ndmps_chain_tail_columns(len(obj.mps.dims), _lib.i64_array(obj.mps.dims))
     assert (n_tail > 0) == (len(obj.mps.dims) >= 2 and obj.mps.dims[-1] <= 4096)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float64", "float32-unfused"])
+@pytest.mark.parametrize("mode,norm", [("Std", False), ("DCT", True)])
+def test_group_paths_of_the_other_storage_types_equal_one_by_one(dtype, mode, norm, monkeypatch):
+    """bf16 / fp64 storage (and fp32 with the fused reshape stage switched off) run the stand-alone reshape stage, the
+    norm and the DCT / IDCT of a lockstep group in one launch each: cores and reconstructions equal the volume-by-volume
+    calls bit for bit."""
+    shape, chi, count = (32, 32, 16, 24), 12, 4
+    if dtype == "float32-unfused":
+        monkeypatch.setenv("NDMPS_NO_FUSED_ENCODE", "1")
+        monkeypatch.setenv("NDMPS_NO_FUSED_DECODE", "1")
+        store = torch.float32
+    else:
+        store = getattr(torch, dtype)
+    vols = [synthetic_mri(shape, seed=70 + i) for i in range(count)]
+    group = NDMPS.from_tensors(vols, mode=mode, norm=norm, max_bond=chi, dtype=store)
+    single = [NDMPS.from_tensor(v, mode=mode, norm=norm, max_bond=chi, dtype=store) for v in vols]
+    for g, s1 in zip(group, single):
+        assert g.bond_sizes() == s1.bond_sizes()
+        assert all(torch.equal(a, b) for a, b in zip(g.mps.cores, s1.mps.cores))
+    together = NDMPS.to_tensors(group, as_torch=True)
+    for g, r in zip(group, together):
+        assert torch.equal(r, g.to_tensor(as_torch=True))
+    as_numpy = NDMPS.to_tensors(group)
+    for g, r in zip(group, as_numpy):
+        assert np.array_equal(r, g.to_tensor())
 
 
 @pytest.mark.parametrize("shape,chi,mode,count", [((64, 64, 64), 16, "Std", 5), ((32, 32, 16, 24), 12, "DCT", 3),
