@@ -72,6 +72,8 @@ def parse(argv=None):
                          "volumes of a group are encoded in lockstep (0 / not given: two from 32 volumes per GPU on, else one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="profiling aid: the timed loop only")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="cube configs: build the objects of a batch before the next batch is enqueued (A/B of the default)")
     ap.add_argument("--no-configs", action="store_true",
                     help="the default line carries short runs of BASELINE configs 2 .. 5 (`configs`); this leaves them out")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -119,17 +121,23 @@ def volume_seeds(job, rank):
     return [job["first_seed"] + j for j in shard_indices(job["n_volumes"], rank, job["world"])]
 
 
-def timed_steps(step, steps, warmup, barrier, reduce_max, after_warmup=None):
+def timed_steps(step, steps, warmup, barrier, reduce_max, after_warmup=None, drain=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier() on both sides (barrier = process
-    group barrier + device synchronise); returns the MAX over ranks of the elapsed seconds."""
+    group barrier + device synchronise); returns the MAX over ranks of the elapsed seconds.  drain: for steps that
+    leave host work pending (the objects of the last batch, see run_cubes): run in front of BOTH barriers, so the timed
+    region holds the host work of exactly K steps."""
     for _ in range(warmup):
         step()
+    if drain is not None:
+        drain()
     if after_warmup is not None:
         after_warmup()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if drain is not None:
+        drain()
     barrier()
     return float(reduce_max(time.perf_counter() - t0))
 
@@ -500,12 +508,31 @@ def run_cubes(ctx):
     pool = ThreadPoolExecutor(groups)
     last = {}
 
-    def step():
-        # wait=False: the step returns when everything is enqueued; the next step queues behind it on the same
-        # streams (like the steps of a training loop) and the barrier of the timed region synchronises the device
-        objs, recs = batch_mod.encode_decode_concurrent(xs, groups=groups, mode=job["mode"], max_bond=job["chi"],
-                                                         pool=pool, wait=False)
+    pipelined = not args.no_pipeline
+
+    def collect(pending):
+        objs, recs = pending.result()
         last["obj"], last["rec"] = objs[0], recs[0]
+
+    def step():
+        # The step returns when everything is enqueued; the next step queues behind it on the same streams (like the
+        # steps of a training loop) and the barrier of the timed region synchronises the device.  Pipelined (the default):
+        # batch k is ENQUEUED (encode_decode_begin), then the NDMPS objects of batch k - 1 are built -- under batch k's
+        # kernels instead of in front of them; drain() below builds the last batch's inside the timed region.
+        # --no-pipeline: the one-call form (objects of batch k built before batch k + 1 is enqueued).
+        if not pipelined:
+            objs, recs = batch_mod.encode_decode_concurrent(xs, groups=groups, mode=job["mode"], max_bond=job["chi"],
+                                                             pool=pool, wait=False)
+            last["obj"], last["rec"] = objs[0], recs[0]
+            return
+        pending = batch_mod.encode_decode_begin(xs, groups=groups, mode=job["mode"], max_bond=job["chi"], pool=pool)
+        previous, last["pending"] = last.get("pending"), pending
+        if previous is not None:
+            collect(previous)
+
+    def drain():
+        if last.get("pending") is not None:
+            collect(last.pop("pending"))
 
     def group_step(vols):  # one lockstep group on the current stream
         objs = NDMPS.from_tensors(vols, mode=job["mode"], max_bond=job["chi"])
@@ -524,7 +551,8 @@ def run_cubes(ctx):
         torch.cuda.synchronize()
         region.resume()
 
-    elapsed = timed_steps(step, args.steps, args.warmup, ctx["barrier"], ctx["reduce_max"], after_warmup=start_profiling)
+    elapsed = timed_steps(step, args.steps, args.warmup, ctx["barrier"], ctx["reduce_max"], after_warmup=start_profiling,
+                          drain=drain)
     region.pause()
     ndmps_mod.set_stage_timer(None)
     _lib.check(lib.ndmps_profile_enable(0))
@@ -545,6 +573,9 @@ def run_cubes(ctx):
         f"{world} GPU(s); {groups} concurrent group(s) per GPU, lockstep inside a group), "
         f"NDMPS.from_tensors(max_bond={job['chi']}, mode={job['mode']}) + to_tensor each, device-resident in/out",
         {"volumes_per_step": job["n_volumes"], "batch_per_gpu": len(xs), "groups_per_gpu": groups,
+         "host_pipeline": ("batch k is enqueued (encode_decode_begin), then the NDMPS objects of batch k - 1 are built; the "
+                           "last batch's objects are built inside the timed region, in front of the closing barrier"
+                           if pipelined else "none (--no-pipeline): objects of batch k built before batch k + 1 is enqueued"),
          "volume_source": f"every volume distinct: seeds {job['first_seed']}..{job['first_seed'] + job['n_volumes'] - 1}, "
                           "block-sharded over the ranks; volume 0 of a rank from the host generator (up to 256^3), the "
                           "rest from its device-side twin (same blobs / shell per seed, torch noise stream)",

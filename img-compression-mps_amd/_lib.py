@@ -120,6 +120,12 @@ SIGNATURES = {
     "ndmps_debug_inject_team_abort": (C.c_int, [C.c_int]),
     "ndmps_debug_lane_sums_f64": (C.c_int, [vp, vp, vp]),
     "ndmps_tt_sweep_pads_cores": (C.c_int, [C.c_int, p_i64, i64]),
+    "ndmps_tt_sweep_async_ints": (i64, [C.c_int, C.c_int]),
+    "ndmps_tt_sweep_async_doubles": (i64, [C.c_int, C.c_int, p_i64, i64]),
+    "ndmps_tt_sweep_batched_fused_begin_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
+                                                         C.POINTER(vp), p_i64, p_i64, vp, vp, vp, vp, vp, i64,
+                                                         vp, i64, vp, vp, vp]),
+    "ndmps_tt_sweep_finish": (C.c_int, [C.c_int, C.c_int, p_i64, i64, vp, vp, p_i64, p_f64, p_i64]),
     "ndmps_tt_sweep_batched_workspace_bytes": (i64, [C.c_int, C.c_int, p_i64, i64]),
     "ndmps_tt_sweep_batched_f32": (C.c_int, [C.c_int, C.POINTER(vp), C.c_int, p_i64, C.c_double, i64,
                                              C.POINTER(vp), p_i64, p_i64, p_f64, p_i64, vp, i64, vp]),

@@ -140,6 +140,68 @@ def encode_decode_concurrent(tensor_list: Sequence, groups: int = None, mode: st
     return objs, (recs if reconstruct else None)
 
 
+class PendingBatch:
+    """What ``encode_decode_begin`` returns: the groups of one batch, enqueued.  ``result()`` -> (objects, reconstructions)
+    in input order, like ``encode_decode_concurrent(wait=False)``: the objects are complete, the reconstructions may still
+    be being written on the groups' streams."""
+
+    def __init__(self, groups, reconstruct):
+        self._groups, self._reconstruct, self._value = groups, reconstruct, None
+
+    def result(self):
+        if self._value is None:
+            objs, recs = [], []
+            for g in self._groups:
+                r = g.result()
+                if self._reconstruct:
+                    objs.extend(r[0])
+                    recs.extend(r[1])
+                else:
+                    objs.extend(r)
+            self._value = (objs, recs if self._reconstruct else None)
+            self._groups = None
+        return self._value
+
+
+def encode_decode_begin(tensor_list: Sequence, groups: int = None, mode: str = "Std", norm: bool = False, max_bond=None,
+                        cutoff: float = 1e-10, reconstruct: bool = True, pool=None):
+    """``encode_decode_concurrent(wait=False)`` in two halves, for a stream of batches: this call ENQUEUES the batch
+    (every group on its own host thread and stream, ``NDMPS.from_tensors_begin``) and returns a ``PendingBatch``; its
+    ``result()`` builds the objects.  A caller that begins batch k + 1 before it asks for the result of batch k has the
+    objects of k built while k + 1 runs -- the Python section behind a sweep (ranks back, 32 objects per group) and the
+    set-up in front of the next one otherwise leave the GPU idle at every batch boundary (1.2 ms of a 27 ms step at 64
+    volumes of 256^3, tools/gap_report.py).  Same kernels in the same order as the one-call form: results are
+    bit-identical."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .ndmps import NDMPS
+
+    tensor_list = list(tensor_list)
+    if groups is None:
+        groups = default_groups(len(tensor_list))
+    parts = _split(len(tensor_list), groups)
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    device_index = torch.cuda.current_device()
+    streams = group_streams(len(parts))
+
+    def work(slot):
+        idx = parts[slot]
+        torch.cuda.set_device(device_index)  # pool threads start on device 0
+        with torch.cuda.stream(streams[slot]):
+            streams[slot].wait_event(ready)  # inputs produced on the caller's stream
+            return NDMPS.from_tensors_begin([tensor_list[i] for i in idx], norm=norm, mode=mode, max_bond=max_bond,
+                                            cutoff=cutoff, reconstruct=reconstruct)
+
+    if pool is None:
+        pool = _group_pools.get(len(parts))
+        if pool is None:
+            pool = _group_pools.setdefault(len(parts), ThreadPoolExecutor(len(parts), thread_name_prefix="ndmps-group"))
+    return PendingBatch(list(pool.map(work, range(len(parts)))), reconstruct)
+
+
 def conv_to_tensors(mps_list: Sequence, as_torch: bool = False):
     """benchmark.py:80-100: reconstruct every NDMPS of the (local) list."""
     from .ndmps import NDMPS

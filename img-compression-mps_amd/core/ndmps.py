@@ -244,6 +244,32 @@ class _GroupState:
         self.partial = None
 
 
+class PendingGroup:
+    """A lockstep group whose sweep and decode are ENQUEUED (``NDMPS.from_tensors_begin``): ``result()`` returns what
+    ``NDMPS.from_tensors`` returns.  Between the two the host thread is free -- ``core/batch.py`` enqueues the next batch
+    before it asks for this one's objects, so their construction runs under the next batch's kernels instead of in
+    front of them.  ``asynchronous`` is False when the group had to be encoded synchronously after all (storage types and
+    shapes whose sweep decides ranks on the host): ``result()`` then only builds the objects."""
+
+    def __init__(self, finish, asynchronous=False, redo=None):
+        self._finish, self._redo, self._value = finish, redo, None
+        self.asynchronous = bool(asynchronous)
+
+    def result(self):
+        if self._value is None:
+            try:
+                value = self._finish()
+            except _lib.NdmpsTeamAbort:
+                # a resident tridiagonalisation gave up (the GPU is shared): the inputs are intact, the group is encoded
+                # again through the synchronous call, which falls back to the per-column launches by itself
+                if self._redo is None:
+                    raise
+                value = self._redo()
+            self._value = (value,)
+            self._finish = self._redo = None
+        return self._value[0]
+
+
 class NDMPS:
     """
     Class for storing and compressing N-dimensional tensors using MPS (device resident).
@@ -421,8 +447,39 @@ class NDMPS:
                 lib.ndmps_syevd_topk_set_team(was)
 
     @classmethod
-    def _encode_group(cls, tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct, mirrored=False):
-        """One lockstep group through norm / DCT / reshape stage / sweep (/ decode): the body of from_tensors."""
+    def from_tensors_begin(cls, tensors, norm: bool = False, mode: str = "Std", max_bond=None, cutoff: float = 1e-10,
+                           device=None, dtype=None, reconstruct: bool = False, sweep_from: str = "right"):
+        """``from_tensors`` in two halves: this one enqueues the group's work on the current stream and returns a
+        ``PendingGroup``; ``result()`` waits for it and returns what ``from_tensors`` returns (same kernels, same order:
+        bit-identical).  For the fp32 bond-capped path nothing on the host waits in between (the sweep decides its ranks
+        on the device: csrc/tt.hip SweepAsync); other paths are encoded here, synchronously, and only build their objects
+        in ``result()``.  The reference has no counterpart (NumPy is synchronous, evaluation/benchmark.py:73-76)."""
+        _lib.require_device()
+        tensors = list(tensors)
+        if not tensors:
+            return PendingGroup(lambda: ([], []) if reconstruct else [])
+        if sweep_from not in ("right", "left"):
+            raise ValueError("sweep_from must be 'right' or 'left'")
+
+        def redo():
+            return cls.from_tensors(tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct, sweep_from)
+
+        try:
+            pend = cls._encode_group(tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct,
+                                     sweep_from == "left", defer=True)
+        except _lib.NdmpsTeamAbort:  # a synchronous path gave up on the resident kernels: from_tensors knows what to do
+            value = redo()
+            return PendingGroup(lambda: value)
+        pend._redo = redo
+        return pend
+
+    @classmethod
+    def _encode_group(cls, tensors, norm, mode, max_bond, cutoff, device, dtype, reconstruct, mirrored=False,
+                      defer=False):
+        """One lockstep group through norm / DCT / reshape stage / sweep (/ decode): the body of from_tensors.
+        ``defer=True`` (from_tensors_begin) returns a ``PendingGroup``: when the sweep decides its ranks on the device
+        (fp32, bond-capped) everything is only ENQUEUED -- sweep, decode, the copies of ranks and spectra into pinned host
+        memory, an event -- and ``result()`` waits for the event, reads the ranks and builds the objects."""
         torch = _torch()
         lib = _lib.load()
         first = tensors[0]
@@ -533,8 +590,22 @@ class NDMPS:
             dense_ptrs = (C.c_void_p * batch)(*[d.data_ptr() for d in denses])
             arena_base, arena_step = arena_all.data_ptr(), core_total * esize
             arena_ptrs = (C.c_void_p * batch)(*[arena_base + b * arena_step for b in range(batch)])
+            padded = bool(lib.ndmps_tt_sweep_pads_cores(L, cdims, mb))
+            # everything a sweep with device-side ranks needs from the host is known now: it can be enqueued whole
+            use_async = bool(defer and gather is not None and padded and L > 1)
+            pin_i = pin_d = done = None
             with _span("sweep"):
-                if gather is not None:
+                if use_async:
+                    row_off, col_off, col_perm = gather
+                    row_sorted, row_order = plan.sorted_rows(n_merge, device)
+                    n_d = int(lib.ndmps_tt_sweep_async_doubles(batch, L, cdims, mb))
+                    pin_i = torch.empty(int(lib.ndmps_tt_sweep_async_ints(batch, L)), dtype=torch.int32, pin_memory=True)
+                    pin_d = torch.empty(max(n_d, 1), dtype=torch.float64, pin_memory=True)
+                    _lib.check(lib.ndmps_tt_sweep_batched_fused_begin_f32(
+                        batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds,
+                        row_off.data_ptr(), row_sorted.data_ptr(), row_order.data_ptr(), col_off.data_ptr(),
+                        col_perm.data_ptr(), n_merge, ws.data_ptr(), ws.numel(), pin_i.data_ptr(), pin_d.data_ptr(), stream))
+                elif gather is not None:
                     row_off, col_off, col_perm = gather
                     row_sorted, row_order = plan.sorted_rows(n_merge, device)
                     _lib.check(lib.ndmps_tt_sweep_batched_fused_f32(
@@ -549,8 +620,7 @@ class NDMPS:
             del ws, denses
             # ranks decided on the device: cores sit in the arena in padded shape (cap_i, d_i, cap_{i+1}), zeros
             # beyond the actual bonds; slicing is a no-op whenever the caps bind (the usual case)
-            padded = bool(lib.ndmps_tt_sweep_pads_cores(L, cdims, mb))
-            bonds_np = np.frombuffer(bonds, dtype=np.int64).reshape(batch, L + 1)
+            bonds_np = np.frombuffer(bonds, dtype=np.int64).reshape(batch, L + 1)  # filled by the sweep / by finish
             spec_np = np.frombuffer(spectra, dtype=np.float64)[: batch * spec_total].reshape(batch, spec_total)
             caps = np.array([int(max_bonds[i]) for i in range(L + 1)], dtype=np.int64)
             offs = [int(core_off[i]) for i in range(L + 1)]
@@ -586,6 +656,21 @@ class NDMPS:
                                                        _dct_basis(n_last, device).data_ptr(), stream))
                     recs = list(rec_all.unbind(0))
                 del cws
+            tstream = torch.cuda.current_stream(device)
+            if use_async:
+                done = torch.cuda.Event()
+                done.record(tstream)
+
+        def finish():
+            """Ranks and spectra to the host (asynchronous sweep: behind its event), objects, state launch."""
+            with torch.cuda.device(device), torch.cuda.stream(tstream):
+                return finish_on_stream()
+
+        def finish_on_stream():
+            if use_async:
+                done.synchronize()
+                _lib.check(lib.ndmps_tt_sweep_finish(batch, L, cdims, mb, pin_i.data_ptr(), pin_d.data_ptr(), bonds, spectra,
+                                                     spec_off))
             per_site = None
             if padded and bool((bonds_np == caps).all()) and not mirrored:
                 # every cap binds: the padded cores ARE the cores; L narrow / view / unbind calls serve the whole
@@ -661,9 +746,13 @@ class NDMPS:
                         o.boundary_list = mm_np[b]
                         # the site that carries the norm: 0 after a right-to-left sweep, L-1 after the mirrored one
                         o.norm_value = np.sqrt(ss[b * L + (L - 1 if mirrored else 0)])
-        if reconstruct:
-            return objs, (recs if recs is not None else cls.to_tensors(objs, as_torch=True))
-        return objs
+            if reconstruct:
+                return objs, (recs if recs is not None else cls.to_tensors(objs, as_torch=True))
+            return objs
+
+        if defer:
+            return PendingGroup(finish, asynchronous=use_async)
+        return finish()
 
     # ----------------------------------------------------------------- bookkeeping
     def astype(self, dtype):

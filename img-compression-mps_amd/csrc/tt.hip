@@ -649,6 +649,38 @@ inline int solver_failed(int site, int volume, int status) {
   return NDMPS_ENOCONV;
 }
 
+// The two halves of a sweep whose ranks are decided on the device: everything such a sweep needs from the host is known
+// before it starts, so it can be ENQUEUED as a whole (SweepAsync: ranks, status words and kept singular values travel to
+// pinned host memory behind the last kernel, nobody waits) and READ later, once the caller has synchronised with the
+// stream (sweep_collect: bonds, spectra, a solver's failure).  The caller's host thread is free in between -- the objects
+// of the previous batch are built while this one runs (core/batch.py).
+struct SweepAsync {
+  int* h_ranks;    // pinned, 2 L batch ints: [site][volume] ranks, then [site][volume] solver status
+  double* h_spec;  // pinned, L batch spec_stride doubles (may be NULL when the layout keeps no spectra)
+};
+int sweep_collect(int batch, int L, int64_t spec_stride, const int* host_i, const double* host_s, int64_t* h_bonds_out,
+                  double* h_spectra, const int64_t* h_spec_offsets) {
+  const int64_t spec_total = h_spec_offsets ? h_spec_offsets[L] : 0;
+  for (int b = 0; b < batch; ++b) {
+    h_bonds_out[(int64_t)b * (L + 1)] = 1;
+    h_bonds_out[(int64_t)b * (L + 1) + L] = 1;
+  }
+  for (int i = 1; i < L; ++i)
+    for (int b = 0; b < batch; ++b) {
+      if (host_i[(size_t)L * batch + (size_t)i * batch + b] != 0)
+        return solver_failed(i, b, host_i[(size_t)L * batch + (size_t)i * batch + b]);
+      h_bonds_out[(int64_t)b * (L + 1) + i] = host_i[(size_t)i * batch + b];
+      if (h_spectra && h_spec_offsets) {
+        const int64_t room = h_spec_offsets[i + 1] - h_spec_offsets[i];
+        double* dst = h_spectra + (int64_t)b * spec_total + h_spec_offsets[i];
+        const int64_t have = std::min(room, spec_stride);
+        for (int64_t t = 0; t < room; ++t)
+          dst[t] = (t < have && host_s) ? host_s[((size_t)i * batch + b) * spec_stride + t] : 0.0;
+      }
+    }
+  return NDMPS_OK;
+}
+
 // A sweep whose input is still intact (the fused one reads the volumes in place) repeats itself on the column
 // launches when a resident tridiagonalisation gave up (NDMPS_ETEAM); the others hand the code to the caller, who
 // owns the site-order copy the sweep has overwritten.
@@ -667,7 +699,7 @@ template <typename T>
 int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, double cutoff, int64_t max_bond,
                T* const* h_cores, const int64_t* h_core_offsets, int64_t* h_bonds_out, double* h_spectra,
                const int64_t* h_spec_offsets, void* d_ws, int64_t ws_bytes, ndmps_stream_t stream,
-               const SweepSource* src = nullptr) {
+               const SweepSource* src = nullptr, const SweepAsync* async = nullptr) {
   NDMPS_REQUIRE(h_dense && h_dims && h_cores && h_core_offsets && h_bonds_out, "NULL sweep argument");
   NDMPS_REQUIRE(cutoff >= 0.0, "cutoff must be non-negative");
   SweepLayout lay;
@@ -1175,26 +1207,24 @@ int sweep_impl(int batch, T* const* h_dense, int L, const int64_t* h_dims, doubl
     NDMPS_CHECK_HIP(hipMemcpyAsync(h_cores[b] + h_core_offsets[0], cur[b], cur_elems[b] * sizeof(T),
                                    hipMemcpyDeviceToDevice, s));
   if (dev_rank && L > 1) {
-    std::vector<int> host_i((size_t)2 * L * batch);
-    std::vector<double> host_s((size_t)L * batch * lay.spec_stride);
-    NDMPS_CHECK_HIP(hipMemcpyAsync(host_i.data(), d_ranks, host_i.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-    if (!host_s.empty())
-      NDMPS_CHECK_HIP(hipMemcpyAsync(host_s.data(), d_spec, host_s.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    const size_t n_i = (size_t)2 * L * batch, n_s = (size_t)L * batch * lay.spec_stride;
+    if (async) {  // enqueue only: the caller reads the pinned buffers behind its own synchronisation (sweep_collect)
+      NDMPS_REQUIRE(async->h_ranks && (async->h_spec || n_s == 0), "asynchronous sweep without its host buffers");
+      NDMPS_CHECK_HIP(hipMemcpyAsync(async->h_ranks, d_ranks, n_i * sizeof(int), hipMemcpyDeviceToHost, s));
+      if (n_s) NDMPS_CHECK_HIP(hipMemcpyAsync(async->h_spec, d_spec, n_s * sizeof(double), hipMemcpyDeviceToHost, s));
+      return NDMPS_OK;
+    }
+    std::vector<int> host_i(n_i);
+    std::vector<double> host_s(n_s);
+    NDMPS_CHECK_HIP(hipMemcpyAsync(host_i.data(), d_ranks, n_i * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (n_s) NDMPS_CHECK_HIP(hipMemcpyAsync(host_s.data(), d_spec, n_s * sizeof(double), hipMemcpyDeviceToHost, s));
     NDMPS_CHECK_HIP(hipStreamSynchronize(s));
-    for (int i = 1; i < L; ++i)
-      for (int b = 0; b < batch; ++b) {
-        if (host_i[(size_t)L * batch + (size_t)i * batch + b] != 0)
-          return solver_failed(i, b, host_i[(size_t)L * batch + (size_t)i * batch + b]);
-        h_bonds_out[(int64_t)b * (L + 1) + i] = host_i[(size_t)i * batch + b];
-        if (h_spectra && h_spec_offsets) {
-          const int64_t room = h_spec_offsets[i + 1] - h_spec_offsets[i];
-          double* dst = h_spectra + (int64_t)b * spec_total + h_spec_offsets[i];
-          const int64_t have = std::min(room, lay.spec_stride);
-          for (int64_t t = 0; t < room; ++t)
-            dst[t] = t < have ? host_s[((size_t)i * batch + b) * lay.spec_stride + t] : 0.0;
-        }
-      }
-    return NDMPS_OK;
+    return sweep_collect(batch, L, lay.spec_stride, host_i.data(), n_s ? host_s.data() : nullptr, h_bonds_out, h_spectra,
+                         h_spec_offsets);
+  }
+  if (async) {
+    ndmps::set_error("an asynchronous sweep needs ranks decided on the device (ndmps_tt_sweep_pads_cores) and more than one site");
+    return NDMPS_EINVAL;
   }
   NDMPS_CHECK_HIP(hipStreamSynchronize(s));
   return NDMPS_OK;
@@ -1248,6 +1278,45 @@ extern "C" int ndmps_tt_sweep_batched_fused_f32(int batch, const float* const* h
     return sweep_impl<float>(batch, (float* const*)h_volume, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets,
                              h_bonds_out, h_spectra, h_spec_offsets, d_ws, ws_bytes, stream, &src);
   });
+}
+
+// The fused sweep in two halves (device-side ranks only: ndmps_tt_sweep_pads_cores; see SweepAsync above).
+//   ..._begin   enqueues the whole sweep and the copies of ranks / status / spectra into the caller's PINNED host buffers
+//               (ndmps_tt_sweep_async_ints / _doubles elements); returns without waiting.  h_bonds_scratch: batch (L + 1).
+//   ndmps_tt_sweep_finish  once the caller has synchronised with the stream (an event behind _begin): bonds, spectra, or
+//               the solver's error -- NDMPS_ETEAM when a resident tridiagonalisation gave up: nothing is repeated here,
+//               the caller redoes the batch with ndmps_tt_sweep_batched_fused_f32 (which retries on the column launches).
+// Reference: the same from_dense of core/ndmps.py:74; the reference has no counterpart of the split (NumPy is synchronous).
+extern "C" int64_t ndmps_tt_sweep_async_ints(int batch, int L) { return (int64_t)2 * L * batch; }
+extern "C" int64_t ndmps_tt_sweep_async_doubles(int batch, int L, const int64_t* h_dims, int64_t max_bond) {
+  SweepLayout lay;
+  if (!h_dims || sweep_layout(L, h_dims, max_bond, batch, lay) != NDMPS_OK) return -1;
+  return (int64_t)L * batch * lay.spec_stride;
+}
+extern "C" int ndmps_tt_sweep_batched_fused_begin_f32(int batch, const float* const* h_volume, int L, const int64_t* h_dims,
+                                                      double cutoff, int64_t max_bond, float* const* h_cores,
+                                                      const int64_t* h_core_offsets, int64_t* h_bonds_scratch,
+                                                      const int64_t* d_row_off, const int64_t* d_row_off_sorted,
+                                                      const int32_t* d_row_order, const int64_t* d_col_off,
+                                                      const int32_t* d_col_perm, int64_t n_cols, void* d_ws, int64_t ws_bytes,
+                                                      int* h_pinned_ranks, double* h_pinned_spec, ndmps_stream_t stream) {
+  NDMPS_REQUIRE(d_row_off && d_col_off && d_col_perm && n_cols >= 1, "NULL permutation table");
+  NDMPS_REQUIRE(h_pinned_ranks != nullptr, "NULL host buffer");
+  SweepSource src{d_row_off, d_row_off_sorted ? d_row_off_sorted : d_row_off, d_row_off_sorted ? d_row_order : nullptr, d_col_off,
+                  d_col_perm, n_cols};
+  const SweepAsync as{h_pinned_ranks, h_pinned_spec};
+  return sweep_impl<float>(batch, (float* const*)h_volume, L, h_dims, cutoff, max_bond, h_cores, h_core_offsets,
+                           h_bonds_scratch, nullptr, nullptr, d_ws, ws_bytes, stream, &src, &as);
+}
+extern "C" int ndmps_tt_sweep_finish(int batch, int L, const int64_t* h_dims, int64_t max_bond, const int* h_pinned_ranks,
+                                     const double* h_pinned_spec, int64_t* h_bonds_out, double* h_spectra,
+                                     const int64_t* h_spec_offsets) {
+  NDMPS_REQUIRE(h_dims && h_pinned_ranks && h_bonds_out && batch >= 1 && L >= 2, "bad sweep_finish argument");
+  SweepLayout lay;
+  NDMPS_TRY(sweep_layout(L, h_dims, max_bond, batch, lay));
+  NDMPS_REQUIRE(lay.device_rank, "this layout decides its ranks on the host: there is nothing to finish");
+  return sweep_collect(batch, L, lay.spec_stride, h_pinned_ranks, lay.spec_stride ? h_pinned_spec : nullptr, h_bonds_out,
+                       h_spectra, h_spec_offsets);
 }
 
 // bf16 storage: the site-order tensors, the carried matrices and the cores are bf16 in HBM; Gram matrices,

@@ -344,6 +344,30 @@ int ndmps_tt_sweep_f32(float* d_dense, int L, const int64_t* h_dims, double cuto
  * (max_bonds[i], d_i, max_bonds[i+1]) with zeros beyond the actual bonds reported in h_bonds_out, and the caller
  * slices them.  0: cores are compact (bonds[i], d_i, bonds[i+1]). */
 int ndmps_tt_sweep_pads_cores(int L, const int64_t* h_dims, int64_t max_bond);
+/* The fused fp32 sweep in two halves, for sweeps that decide their ranks on the device (ndmps_tt_sweep_pads_cores = 1,
+ * L > 1): everything such a sweep needs from the host is known before it starts.
+ *   ndmps_tt_sweep_batched_fused_begin_f32  ENQUEUES the whole sweep (arguments as ndmps_tt_sweep_batched_fused_f32) and the
+ *       copies of ranks, solver status and kept singular values into the caller's PINNED host buffers
+ *       (h_pinned_ranks: ndmps_tt_sweep_async_ints(batch, L) ints; h_pinned_spec: ndmps_tt_sweep_async_doubles(...)
+ *       doubles, may be a dummy when that is 0); does not wait.  h_bonds_scratch: batch (L + 1) entries.
+ *   ndmps_tt_sweep_finish  after the caller has synchronised with the stream (an event behind _begin): fills h_bonds_out
+ *       and h_spectra like the one-call form, or returns the solver's error -- NDMPS_ETEAM when a resident
+ *       tridiagonalisation gave up; nothing is repeated here: the volumes are intact, the caller redoes the batch with
+ *       ndmps_tt_sweep_batched_fused_f32, which retries on the column launches.
+ * Replaces the same MatrixProductState.from_dense (core/ndmps.py:74); the reference has no counterpart of the split (NumPy
+ * is synchronous).  core/batch.py begins batch k + 1 before it reads batch k: the objects of k are built under k + 1. */
+int64_t ndmps_tt_sweep_async_ints(int batch, int L);
+int64_t ndmps_tt_sweep_async_doubles(int batch, int L, const int64_t* h_dims, int64_t max_bond);
+int ndmps_tt_sweep_batched_fused_begin_f32(int batch, const float* const* h_volume, int L, const int64_t* h_dims,
+                                           double cutoff, int64_t max_bond, float* const* h_cores,
+                                           const int64_t* h_core_offsets, int64_t* h_bonds_scratch,
+                                           const int64_t* d_row_off, const int64_t* d_row_off_sorted,
+                                           const int32_t* d_row_order, const int64_t* d_col_off,
+                                           const int32_t* d_col_perm, int64_t n_cols, void* d_ws, int64_t ws_bytes,
+                                           int* h_pinned_ranks, double* h_pinned_spec, ndmps_stream_t stream);
+int ndmps_tt_sweep_finish(int batch, int L, const int64_t* h_dims, int64_t max_bond, const int* h_pinned_ranks,
+                          const double* h_pinned_spec, int64_t* h_bonds_out, double* h_spectra,
+                          const int64_t* h_spec_offsets);
 int64_t ndmps_tt_sweep_batched_workspace_bytes(int batch, int L, const int64_t* h_dims,
                                                int64_t max_bond);
 int ndmps_tt_sweep_batched_f32(int batch, float* const* h_dense, int L, const int64_t* h_dims,

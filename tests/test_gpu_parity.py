@@ -1088,6 +1088,48 @@ def test_from_tensors_equals_from_tensor_one_by_one():
     assert NDMPS.from_tensors([]) == []
 
 
+@pytest.mark.parametrize("shape,chi,mode,norm,enqueued", [((64, 64, 64), 16, "Std", False, True),
+                                                           ((128, 128, 128), 32, "DCT", True, True),
+                                                           ((32, 32, 16, 24), 12, "Std", False, False),  # no merged run
+                                                           ((48, 40, 36), None, "Std", False, False)], ids=str)
+def test_from_tensors_in_two_halves_equals_the_one_call_form(shape, chi, mode, norm, enqueued):
+    """from_tensors_begin enqueues sweep and decode (the fp32 bond-capped sweep decides its ranks on the device: nothing on
+    the host waits), result() reads the ranks behind an event and builds the objects: the same kernels in the same order
+    as from_tensors -- cores, bonds, spectra, state and reconstructions are bit-identical, also when a second batch is
+    begun before the first one's result is asked for; exact sweeps (host-side ranks) take the synchronous route."""
+    from imgcompressionmps_amd.core import batch as hbatch
+
+    vols = [dev(synthetic_mri(shape, seed=90 + i)) for i in range(5)]
+    want_objs, want_recs = NDMPS.from_tensors(vols, mode=mode, norm=norm, max_bond=chi, reconstruct=True)
+    first = NDMPS.from_tensors_begin(vols, mode=mode, norm=norm, max_bond=chi, reconstruct=True)
+    second = NDMPS.from_tensors_begin(vols[::-1], mode=mode, norm=norm, max_bond=chi, reconstruct=True)
+    assert first.asynchronous == enqueued
+    objs, recs = first.result()
+    assert first.result()[0] is objs  # a second call returns the same objects
+    objs2, recs2 = second.result()
+    for got_o, got_r in ((objs, recs), (objs2[::-1], recs2[::-1])):
+        for a, b, ra, rb in zip(want_objs, got_o, want_recs, got_r):
+            assert a.bond_sizes() == b.bond_sizes()
+            assert all(torch.equal(x, y) for x, y in zip(a.mps.cores, b.mps.cores))
+            assert torch.equal(ra, rb)
+            assert np.array_equal(np.asarray(a.boundary_list), np.asarray(b.boundary_list))
+            assert a.norm_value == b.norm_value
+            sa, sb = a.sweep_spectra, b.sweep_spectra
+            assert all((x is None and y is None) or np.array_equal(x, y) for x, y in zip(sa, sb))
+    assert NDMPS.from_tensors_begin([]).result() == [] and NDMPS.from_tensors_begin([], reconstruct=True).result() == ([], [])
+    only = NDMPS.from_tensors_begin(vols[:2], mode=mode, norm=norm, max_bond=chi).result()
+    assert all(torch.equal(x, y) for a, b in zip(want_objs[:2], only) for x, y in zip(a.mps.cores, b.mps.cores))
+    # the batch layer: two groups on their own streams, a second batch begun before the first is read
+    one = hbatch.encode_decode_concurrent(vols[:4], groups=2, mode=mode, norm=norm, max_bond=chi)
+    p1 = hbatch.encode_decode_begin(vols[:4], groups=2, mode=mode, norm=norm, max_bond=chi)
+    p2 = hbatch.encode_decode_begin(vols[:4], groups=2, mode=mode, norm=norm, max_bond=chi)
+    for pend in (p1, p2):
+        o, r = pend.result()
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(one[1], r))
+        assert all(torch.equal(x, y) for a, b in zip(one[0], o) for x, y in zip(a.mps.cores, b.mps.cores))
+
+
 def test_streams_create_returns_usable_distinct_streams():
     lib = _lib.load()
     raw = (C.c_void_p * 4)()
