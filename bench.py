@@ -72,6 +72,10 @@ def parse(argv=None):
                          "volumes of a group are encoded in lockstep (0 / not given: two from 32 volumes per GPU on, else one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-single", action="store_true", help="profiling aid: the timed loop only")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="cube configs: sets of streams that consecutive batches alternate between (0: core/batch.py "
+                         "default_lanes -- three when a batch is one lockstep group, two for two groups of eigenproblems of "
+                         "order <= 256, else one)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="cube configs: build the objects of a batch before the next batch is enqueued (A/B of the default)")
     ap.add_argument("--no-configs", action="store_true",
@@ -509,6 +513,12 @@ def run_cubes(ctx):
     last = {}
 
     pipelined = not args.no_pipeline
+    # consecutive batches of ONE lockstep group each (fewer than 32 volumes per GPU: a rank of a strong-scaling run) alternate
+    # between three sets of streams, so that they overlap on the GPU the way the two groups of a large batch do
+    lanes = max(1, args.lanes) if args.lanes else batch_mod.default_lanes(groups, min(8 * job["chi"], 512))
+    if not pipelined:
+        lanes = 1
+    in_flight, counter = [], [0]
 
     def collect(pending):
         objs, recs = pending.result()
@@ -525,14 +535,15 @@ def run_cubes(ctx):
                                                              pool=pool, wait=False)
             last["obj"], last["rec"] = objs[0], recs[0]
             return
-        pending = batch_mod.encode_decode_begin(xs, groups=groups, mode=job["mode"], max_bond=job["chi"], pool=pool)
-        previous, last["pending"] = last.get("pending"), pending
-        if previous is not None:
-            collect(previous)
+        in_flight.append(batch_mod.encode_decode_begin(xs, groups=groups, mode=job["mode"], max_bond=job["chi"], pool=pool,
+                                                       lane=counter[0], lanes=lanes))
+        counter[0] += 1
+        while len(in_flight) > lanes:
+            collect(in_flight.pop(0))
 
     def drain():
-        if last.get("pending") is not None:
-            collect(last.pop("pending"))
+        while in_flight:
+            collect(in_flight.pop(0))
 
     def group_step(vols):  # one lockstep group on the current stream
         objs = NDMPS.from_tensors(vols, mode=job["mode"], max_bond=job["chi"])
@@ -573,8 +584,9 @@ def run_cubes(ctx):
         f"{world} GPU(s); {groups} concurrent group(s) per GPU, lockstep inside a group), "
         f"NDMPS.from_tensors(max_bond={job['chi']}, mode={job['mode']}) + to_tensor each, device-resident in/out",
         {"volumes_per_step": job["n_volumes"], "batch_per_gpu": len(xs), "groups_per_gpu": groups,
-         "host_pipeline": ("batch k is enqueued (encode_decode_begin), then the NDMPS objects of batch k - 1 are built; the "
-                           "last batch's objects are built inside the timed region, in front of the closing barrier"
+         "host_pipeline": (f"batch k is enqueued (encode_decode_begin, lane k mod {lanes} of {lanes} set(s) of streams), then "
+                           f"the NDMPS objects of batch k - {lanes} are built; the last batches' objects are built inside the "
+                           "timed region, in front of the closing barrier"
                            if pipelined else "none (--no-pipeline): objects of batch k built before batch k + 1 is enqueued"),
          "volume_source": f"every volume distinct: seeds {job['first_seed']}..{job['first_seed'] + job['n_volumes'] - 1}, "
                           "block-sharded over the ranks; volume 0 of a rank from the host generator (up to 256^3), the "
@@ -721,7 +733,35 @@ def extras_cubes(ctx, line, xs, x, shape, n_vox, group_step, single_step, ms_per
     # BASELINE config 4's question asked of ONE GPU: 64 volumes in total over 8 GPUs put 8 on each; the best a perfect
     # 8-GPU run can do is t(64 volumes) / t(8 volumes), both measured here on one GPU.  Not a measured scaling curve.
     if job["config"] == "metric" and not args_overridden(args) and ctx["world"] == 1 and len(xs) >= 64:
-        proj = {"256^3 chi=64": {"ms_64_volumes": ms_per_step, "ms_8_volumes": group8_ms, "ratio": ms_per_step / group8_ms}}
+        def streamed_ms(vols, chi, batches=24):
+            """ms per batch of a STREAM of such batches (what a rank of a strong-scaling run sees step after step):
+            encode_decode_begin on default_lanes() alternating sets of streams, objects built `lanes` batches later."""
+            n_groups = batch_mod.default_groups(len(vols))
+            n_lanes = batch_mod.default_lanes(n_groups, min(8 * chi, 512))
+            flight = []
+
+            def go(k):
+                flight.append(batch_mod.encode_decode_begin(vols, groups=n_groups, mode="Std", max_bond=chi, lane=k,
+                                                            lanes=n_lanes))
+                while len(flight) > n_lanes:
+                    flight.pop(0).result()
+
+            for k in range(2 * n_lanes):
+                go(k)
+            while flight:
+                flight.pop(0).result()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(batches):
+                go(k)
+            while flight:
+                flight.pop(0).result()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / batches * 1e3
+
+        s8 = streamed_ms(xs[:n8], job["chi"])
+        proj = {"256^3 chi=64": {"ms_64_volumes": ms_per_step, "ms_8_volumes": group8_ms, "ratio": ms_per_step / group8_ms,
+                                 "ms_8_volumes_streamed": s8, "ratio_streamed": ms_per_step / s8}}
         small = [synthetic_mri_device((128, 128, 128), FIRST_SEED + j, device) for j in range(64)]
 
         def small_step(vols, groups):
@@ -736,9 +776,15 @@ def extras_cubes(ctx, line, xs, x, shape, n_vox, group_step, single_step, ms_per
                 small_step(vols, groups)
             torch.cuda.synchronize()
             times[name] = (time.perf_counter() - t0) / 5 * 1e3
-        proj["128^3 chi=32"] = {"ms_64_volumes": times["64"], "ms_8_volumes": times["8"], "ratio": times["64"] / times["8"]}
+        s8 = streamed_ms(small[:8], 32)
+        s64 = streamed_ms(small, 32, batches=12)
+        proj["128^3 chi=32"] = {"ms_64_volumes": times["64"], "ms_8_volumes": times["8"], "ratio": times["64"] / times["8"],
+                                "ms_64_volumes_streamed": s64, "ms_8_volumes_streamed": s8, "ratio_streamed": s64 / s8}
         proj["note"] = ("upper bound of the 8-GPU speed-up on 64 volumes in total (8 per GPU): time of 64 volumes / time of "
-                        "8 volumes, both on this one GPU; no multi-GPU run is behind it")
+                        "8 volumes, both on this one GPU; no multi-GPU run is behind it.  `ratio`: one batch alone, waited "
+                        "for (latency); `ratio_streamed`: batch after batch (steady state of the timed loop of `bench.py "
+                        "--total-volumes 64 --gpus 8`: consecutive batches alternate between three sets of streams, "
+                        "core/batch.py default_lanes)")
         line["strong_scaling_projection"] = proj
         del small
 

@@ -48,6 +48,20 @@ def default_groups(n_items: int) -> int:
     return 2 if n_items >= 32 else 1
 
 
+def default_lanes(groups: int, eig_order: int = 512) -> int:
+    """Sets of streams that the consecutive batches of a STREAM of batches alternate between (``encode_decode_begin``):
+    batch k runs on lane k mod lanes, so consecutive batches overlap on the GPU the way the groups of one batch do.
+    Measured on one MI355X (256^3 chi = 64, ms per batch, one / two / three lanes): 8 volumes 9.7 / 6.8 / 6.0, 16 volumes
+    12.7 / 8.2 / 7.3, 31 volumes 16.9 / 13.4 / 12.7; 128^3 chi = 32: 8 volumes 3.2 / 1.8 / 1.3.  Batches of two groups (from
+    32 volumes on) gain from a second lane only while the resident tridiagonalisations of a group take half a turn
+    (eigenproblems of order <= 256: 64 volumes of 256^3 chi = 32 12.1 -> 10.8 ms, of 128^3 4.9 -> 3.7 ms); four groups of
+    32 order-512 matrices in flight -- four full turns, five streams on four hardware queues -- collapse (27 -> 118 ms
+    per batch), so those keep one lane."""
+    if groups <= 1:
+        return 3
+    return 2 if eig_order <= 256 else 1
+
+
 def _split(n_items: int, groups: int):
     groups = max(1, min(groups, n_items))
     return [shard_indices(n_items, g, groups) for g in range(groups)]
@@ -164,14 +178,16 @@ class PendingBatch:
 
 
 def encode_decode_begin(tensor_list: Sequence, groups: int = None, mode: str = "Std", norm: bool = False, max_bond=None,
-                        cutoff: float = 1e-10, reconstruct: bool = True, pool=None):
+                        cutoff: float = 1e-10, reconstruct: bool = True, pool=None, lane: int = 0, lanes: int = 1):
     """``encode_decode_concurrent(wait=False)`` in two halves, for a stream of batches: this call ENQUEUES the batch
     (every group on its own host thread and stream, ``NDMPS.from_tensors_begin``) and returns a ``PendingBatch``; its
     ``result()`` builds the objects.  A caller that begins batch k + 1 before it asks for the result of batch k has the
     objects of k built while k + 1 runs -- the Python section behind a sweep (ranks back, 32 objects per group) and the
     set-up in front of the next one otherwise leave the GPU idle at every batch boundary (1.2 ms of a 27 ms step at 64
     volumes of 256^3, tools/gap_report.py).  Same kernels in the same order as the one-call form: results are
-    bit-identical."""
+    bit-identical.
+    ``lane`` / ``lanes``: a stream of SMALL batches (one group each) may alternate between ``lanes`` sets of streams --
+    batch k on lane k mod lanes -- so that consecutive batches overlap on the GPU the way two groups of one batch do."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
 
@@ -185,7 +201,8 @@ def encode_decode_begin(tensor_list: Sequence, groups: int = None, mode: str = "
     ready = torch.cuda.Event()
     ready.record(main)
     device_index = torch.cuda.current_device()
-    streams = group_streams(len(parts))
+    lanes = max(1, int(lanes))
+    streams = group_streams(len(parts) * lanes)[(int(lane) % lanes) * len(parts):]
 
     def work(slot):
         idx = parts[slot]
