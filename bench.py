@@ -105,9 +105,12 @@ def job_descriptor(args, world):
     n_volumes = int(args.total_volumes) if strong else int(args.batch) * int(world)
     per_gpu = -(-n_volumes // int(world)) if strong else int(args.batch)
     groups = int(args.groups)
-    if groups <= 0:  # not given: what the library would pick for this many volumes per GPU (core/batch.default_groups)
-        from imgcompressionmps_amd.core.batch import default_groups
-        groups = default_groups(per_gpu)
+    if groups <= 0:  # not given: what the library would pick for this many volumes per GPU
+        from imgcompressionmps_amd.core.batch import default_groups, default_stream_shape
+        if getattr(args, "kind", "cubes") == "cubes" and not getattr(args, "no_pipeline", False):
+            groups = default_stream_shape(per_gpu, min(8 * int(args.chi), 512))[0]  # batch after batch (run_cubes)
+        else:
+            groups = default_groups(per_gpu)
     return {"config": str(getattr(args, "config", "metric")), "kind": str(getattr(args, "kind", "cubes")),
             "shape": [int(v) for v in getattr(args, "shape", (args.size,) * 3)],
             "size": int(args.size), "chi": int(args.chi), "mode": str(args.mode),
@@ -515,7 +518,9 @@ def run_cubes(ctx):
     pipelined = not args.no_pipeline
     # consecutive batches of ONE lockstep group each (fewer than 32 volumes per GPU: a rank of a strong-scaling run) alternate
     # between three sets of streams, so that they overlap on the GPU the way the two groups of a large batch do
-    lanes = max(1, args.lanes) if args.lanes else batch_mod.default_lanes(groups, min(8 * job["chi"], 512))
+    eig_order = min(8 * job["chi"], 512)
+    lanes = max(1, args.lanes) if args.lanes else (
+        batch_mod.default_stream_shape(len(xs), eig_order)[1] if int(args.groups) <= 0 else batch_mod.default_lanes(groups, eig_order))
     if not pipelined:
         lanes = 1
     in_flight, counter = [], [0]
@@ -562,6 +567,13 @@ def run_cubes(ctx):
         torch.cuda.synchronize()
         region.resume()
 
+    # set-up, not a step: every lane's streams get their buffers from the caching allocator (its pools are per stream, and a
+    # lane holds two batches' reconstructions at a time: with W = 2 warm-up steps the third lane would meet fresh hipMallocs
+    # of several GB inside the timed region)
+    for _ in range(2 * lanes if lanes > 1 else 0):
+        step()
+    drain()
+    torch.cuda.synchronize()
     elapsed = timed_steps(step, args.steps, args.warmup, ctx["barrier"], ctx["reduce_max"], after_warmup=start_profiling,
                           drain=drain)
     region.pause()
@@ -587,6 +599,8 @@ def run_cubes(ctx):
          "host_pipeline": (f"batch k is enqueued (encode_decode_begin, lane k mod {lanes} of {lanes} set(s) of streams), then "
                            f"the NDMPS objects of batch k - {lanes} are built; the last batches' objects are built inside the "
                            "timed region, in front of the closing barrier"
+                           + (f"; set-up ran two untimed batches per lane ({2 * lanes}) so that every lane's allocator pool is "
+                              "filled" if lanes > 1 else "")
                            if pipelined else "none (--no-pipeline): objects of batch k built before batch k + 1 is enqueued"),
          "volume_source": f"every volume distinct: seeds {job['first_seed']}..{job['first_seed'] + job['n_volumes'] - 1}, "
                           "block-sharded over the ranks; volume 0 of a rank from the host generator (up to 256^3), the "

@@ -62,6 +62,16 @@ def default_lanes(groups: int, eig_order: int = 512) -> int:
     return 2 if eig_order <= 256 else 1
 
 
+def default_stream_shape(n_items: int, eig_order: int = 512):
+    """(groups, lanes) for a STREAM of batches of ``n_items`` same-shape volumes (``encode_decode_begin`` batch after batch):
+    ONE lockstep group on three lanes at every size measured -- three batches in different phases overlap better than the two
+    groups of one batch, and every launch serves the whole batch.  Measured, 64 volumes per batch, ms per batch (groups,
+    lanes): 256^3 chi = 64: (2, 1) 27.0, (1, 3) 25.1 - 25.7, (1, 4) 26.2; 256^3 chi = 32: (2, 1) 12.1, (2, 2) 10.7, (1, 3) 9.9;
+    128^3 chi = 32: (2, 1) 4.9, (2, 2) 4.5, (1, 3) 4.1 - 4.5.  One call that waits for its batch (encode_decode_concurrent)
+    keeps default_groups."""
+    return 1, 3
+
+
 def _split(n_items: int, groups: int):
     groups = max(1, min(groups, n_items))
     return [shard_indices(n_items, g, groups) for g in range(groups)]

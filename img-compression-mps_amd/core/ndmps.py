@@ -617,7 +617,10 @@ class NDMPS:
                              lib.ndmps_tt_sweep_batched_f64 if f64 else lib.ndmps_tt_sweep_batched_f32)
                     _lib.check(sweep(batch, dense_ptrs, L, cdims, float(cutoff), mb, arena_ptrs, core_off, bonds,
                                      spectra, spec_off, ws.data_ptr(), ws.numel(), stream))
-            del ws, denses
+            del denses
+            # (the workspace is released further down, behind the decode's buffers: freed here, the caching allocator cut the
+            # reconstruction buffer out of its block whenever earlier reconstructions were still held by a pending batch,
+            # and the next batch's workspace -- several GB -- came from a fresh hipMalloc: one second, now and then)
             # ranks decided on the device: cores sit in the arena in padded shape (cap_i, d_i, cap_{i+1}), zeros
             # beyond the actual bonds; slicing is a no-op whenever the caps bind (the usual case)
             bonds_np = np.frombuffer(bonds, dtype=np.int64).reshape(batch, L + 1)  # filled by the sweep / by finish
@@ -656,6 +659,7 @@ class NDMPS:
                                                        _dct_basis(n_last, device).data_ptr(), stream))
                     recs = list(rec_all.unbind(0))
                 del cws
+            del ws
             tstream = torch.cuda.current_stream(device)
             if use_async:
                 done = torch.cuda.Event()

@@ -231,16 +231,22 @@ def test_bench_strong_scaling_mode_world_size_2_gloo():
 
 
 def test_group_count_follows_the_volumes_per_gpu():
-    """core/batch.default_groups: two concurrent lockstep groups from 32 volumes per GPU on, one below; the bench takes
-    it per rank when --groups is not given -- weak scaling keeps two groups of 32, BASELINE's 64 volumes in total over 8
-    GPUs run as one group of 8 per GPU -- and an explicit --groups wins."""
+    """core/batch.default_groups (one call that waits for its batch): two concurrent lockstep groups from 32 volumes per GPU
+    on, one below.  core/batch.default_stream_shape (batch after batch, what the bench's timed loop does): (groups, lanes) =
+    one group on three sets of streams.  The bench takes the stream shape per rank when --groups is not given (the one-call count under
+    --no-pipeline), and an explicit --groups wins."""
     import bench
-    from imgcompressionmps_amd.core.batch import default_groups
+    from imgcompressionmps_amd.core.batch import default_groups, default_lanes, default_stream_shape
 
     assert [default_groups(n) for n in (1, 8, 24, 31, 32, 64, 128)] == [1, 1, 1, 1, 2, 2, 2]
-    assert bench.job_descriptor(bench.parse([]), 1)["groups"] == 2
-    assert bench.job_descriptor(bench.parse([]), 8)["groups"] == 2
+    assert [default_stream_shape(n, 512) for n in (1, 8, 31, 32, 64)] == [(1, 3)] * 5
+    assert [default_stream_shape(n, 256) for n in (8, 31, 32, 64)] == [(1, 3)] * 4
+    assert [default_lanes(g, o) for g, o in ((1, 512), (2, 512), (2, 256), (4, 256))] == [3, 1, 2, 2]
+    assert bench.job_descriptor(bench.parse([]), 1)["groups"] == 1  # 64 volumes of 256^3, chi = 64: order-512 eigenproblems
+    assert bench.job_descriptor(bench.parse([]), 8)["groups"] == 1
+    assert bench.job_descriptor(bench.parse(["--no-pipeline"]), 1)["groups"] == 2
+    assert bench.job_descriptor(bench.parse(["--config", "2"]), 1)["groups"] == 1  # 64 x 256^3, chi = 32: order 256
     strong = bench.job_descriptor(bench.parse(["--total-volumes", "64"]), 8)
     assert strong["batch_per_gpu"] == 8 and strong["groups"] == 1 and strong["scaling"] == "strong"
-    assert bench.job_descriptor(bench.parse(["--total-volumes", "64"]), 2)["groups"] == 2
+    assert bench.job_descriptor(bench.parse(["--total-volumes", "64", "--no-pipeline"]), 2)["groups"] == 2
     assert bench.job_descriptor(bench.parse(["--total-volumes", "64", "--groups", "4"]), 8)["groups"] == 4
