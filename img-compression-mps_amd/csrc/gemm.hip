@@ -1758,7 +1758,11 @@ int gram128_batched(int batch, const TIN* const* h_A, int64_t m, int64_t n, int6
   // a launch that fills the GPU for milliseconds (a lockstep group's raw Gram) takes its turn with those of other
   // streams: two of them at once gain nothing (both MFMA-bound) and keep each other's groups in phase
   const bool turn = (int64_t)batch * g.slots >= 4096 && !getenv("NDMPS_GRAM_NO_TURN");
-  ndmps::Turn gram_turn(s, ndmps::kTurnGram);
+  // NDMPS_ONE_TURN=1 (A/B): the Gram launches take the resident tridiagonalisations' lock, whole -- with several batches in
+  // flight (core/batch.py lanes) a Gram launch and a resident launch of another batch otherwise run together and slow each
+  // other (both fp64: one pipeline)
+  static const bool one_turn = getenv("NDMPS_ONE_TURN") != nullptr;
+  ndmps::Turn gram_turn(s, one_turn ? ndmps::kTurnTeam : ndmps::kTurnGram, one_turn ? 2u : 1u, one_turn ? 2u : 1u);
   if (turn) NDMPS_TRY(gram_turn.begin());
   void* span = ndmps::span_begin(s);
   for (int base = 0; base < batch; base += kGram128MaxBatch) {

@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace ndmps
 
-extern "C" int ndmps_version(void) { return 104; }  // round 4: direct solver for any k <= n <= 4096, potrf, per-slice SSIM, team slots
+extern "C" int ndmps_version(void) { return 105; }  // round 4: direct solver for any k <= n <= 4096, potrf, per-slice SSIM, team slots; 105: sweep in two halves, group-wide permute / DCT / scaling
 
 extern "C" const char* ndmps_last_error(void) { return ndmps::g_err; }
 
