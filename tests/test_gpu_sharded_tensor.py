@@ -272,3 +272,37 @@ def test_bench_config_5_on_two_ranks_sharing_the_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["workload"].startswith("ONE 128x128x64x256")
+
+
+@pytest.mark.parametrize("flags", [[], ["--no-pipeline"], ["--total-volumes", "8"]], ids=["stream", "one-call", "strong"])
+def test_bench_cube_config_on_two_ranks_sharing_the_gpu(flags):
+    """The driver's multi-GPU command for the headline path (independent volumes sharded over the ranks, no data-path
+    collective), rehearsed the way this box allows: two ranks over gloo, both on cuda:0, small volumes.  Batches issued as
+    a stream (the default: encode_decode_begin on three lanes, objects built two batches later), one call per batch
+    (--no-pipeline) and strong scaling (8 volumes in total, 4 per rank); rank 0 prints one JSON line with the whole job's
+    throughput."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+           "--size", "64", "--chi", "16", "--batch", "6", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-configs",
+           "--skip-single"] + flags
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    strong = "--total-volumes" in flags
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 4
+    assert line["scaling"] == ("strong" if strong else "weak")
+    assert line["config"]["volumes_per_step"] == (8 if strong else 12)
+    assert line["team_fallbacks"] == 0
+    assert ("none" in line["config"]["host_pipeline"]) == ("--no-pipeline" in flags)
+    # throughput counts the job's volumes once: volumes x voxels / time
+    assert line["value"] == pytest.approx(line["config"]["volumes_per_step"] * 64 ** 3 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
