@@ -251,9 +251,18 @@ class PendingGroup:
     front of them.  ``asynchronous`` is False when the group had to be encoded synchronously after all (storage types and
     shapes whose sweep decides ranks on the host): ``result()`` then only builds the objects."""
 
-    def __init__(self, finish, asynchronous=False, redo=None):
-        self._finish, self._redo, self._value = finish, redo, None
+    def __init__(self, finish, asynchronous=False, redo=None, wait=None):
+        self._finish, self._redo, self._value, self._wait = finish, redo, None, wait
         self.asynchronous = bool(asynchronous)
+
+    def __del__(self):
+        # dropped without result(): the copies of ranks and spectra into this group's pinned buffers may still be in
+        # flight -- wait for them before the buffers go back to the host allocator
+        if self._value is None and self._wait is not None:
+            try:
+                self._wait()
+            except Exception:
+                pass
 
     def result(self):
         if self._value is None:
@@ -266,7 +275,7 @@ class PendingGroup:
                     raise
                 value = self._redo()
             self._value = (value,)
-            self._finish = self._redo = None
+            self._finish = self._redo = self._wait = None
         return self._value[0]
 
 
@@ -755,7 +764,7 @@ class NDMPS:
             return objs
 
         if defer:
-            return PendingGroup(finish, asynchronous=use_async)
+            return PendingGroup(finish, asynchronous=use_async, wait=done.synchronize if use_async else None)
         return finish()
 
     # ----------------------------------------------------------------- bookkeeping

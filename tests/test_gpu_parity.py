@@ -1117,6 +1117,8 @@ def test_from_tensors_in_two_halves_equals_the_one_call_form(shape, chi, mode, n
             sa, sb = a.sweep_spectra, b.sweep_spectra
             assert all((x is None and y is None) or np.array_equal(x, y) for x, y in zip(sa, sb))
     assert NDMPS.from_tensors_begin([]).result() == [] and NDMPS.from_tensors_begin([], reconstruct=True).result() == ([], [])
+    dropped = NDMPS.from_tensors_begin(vols, mode=mode, norm=norm, max_bond=chi, reconstruct=True)
+    del dropped  # never read: waits for its copies into pinned memory, nothing else
     only = NDMPS.from_tensors_begin(vols[:2], mode=mode, norm=norm, max_bond=chi).result()
     assert all(torch.equal(x, y) for a, b in zip(want_objs[:2], only) for x, y in zip(a.mps.cores, b.mps.cores))
     # the batch layer: two groups on their own streams, a second batch begun before the first is read
