@@ -17,6 +17,8 @@ n, k = 512, 64
 lib = _lib.load()
 burn = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libcorun.so"))
 burn.corun_burn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+burn.corun_burn32.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+FP32 = os.environ.get("CORUN_FP32") is not None  # the fp32-MFMA burner instead of the fp64 one
 dev = "cuda:0"
 gen = torch.Generator(device=dev).manual_seed(1)
 a = torch.randn((B, n + 64, n), dtype=torch.float64, device=dev, generator=gen)
@@ -38,7 +40,8 @@ def values(stream):
 
 
 def burner(iters):
-    assert burn.corun_burn(wgs, iters, lds_kb * 1024, src.data_ptr(), out.data_ptr(), s2.cuda_stream) == 0
+    fn = burn.corun_burn32 if FP32 else burn.corun_burn
+    assert fn(wgs, iters, lds_kb * 1024, src.data_ptr(), out.data_ptr(), s2.cuda_stream) == 0
 
 
 def ev():
@@ -65,7 +68,7 @@ burner(iters)
 e1.record(s2)
 torch.cuda.synchronize()
 b_alone = e0.elapsed_time(e1)
-flop = wgs * 4 * iters * 32 * 2048
+flop = wgs * 4 * iters * 32 * (4096 if FP32 else 2048)
 print(f"alone: tridiagonalisation + eigenvalues of {B} matrices {t_alone:.3f} ms; burner ({wgs} workgroups, {lds_kb} KB LDS) "
       f"{b_alone:.3f} ms = {flop / b_alone / 1e9:.1f} TFLOP/s", flush=True)
 # together: the burner first, then three reductions back to back while it runs
