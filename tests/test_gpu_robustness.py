@@ -373,3 +373,33 @@ def test_the_solver_switch_is_per_host_thread(lib):
         assert np.array_equal(a, b)
     for a, b in zip(columns, seen["columns"]):
         assert np.array_equal(a, b)
+
+
+def test_a_pending_group_redoes_itself_when_a_resident_launch_gave_up(monkeypatch):
+    """from_tensors_begin enqueues a sweep whose solver status is only read in result(): when that status says a resident
+    tridiagonalisation gave up (NDMPS_ETEAM from ndmps_tt_sweep_finish -- injected here on the host side, no 3-s spin), the
+    volumes are intact and the group is encoded again through the one-call form; the caller gets the same objects and
+    reconstructions as from from_tensors, and a later group is not affected."""
+    from oracle.metrics import synthetic_mri
+
+    lib = _lib.load()
+    vols = [torch.from_numpy(synthetic_mri((64, 64, 64), seed=300 + i)).to(DEV) for i in range(4)]
+    want_objs, want_recs = NDMPS.from_tensors(vols, max_bond=16, reconstruct=True)
+    real = lib.ndmps_tt_sweep_finish
+    calls = []
+
+    def gave_up(*args):
+        calls.append(1)
+        return _lib.ETEAM if len(calls) == 1 else real(*args)
+
+    monkeypatch.setattr(lib, "ndmps_tt_sweep_finish", gave_up)
+    first = NDMPS.from_tensors_begin(vols, max_bond=16, reconstruct=True)
+    second = NDMPS.from_tensors_begin(vols, max_bond=16, reconstruct=True)
+    assert first.asynchronous and second.asynchronous
+    for pend in (first, second):
+        objs, recs = pend.result()
+        for a, b, ra, rb in zip(want_objs, objs, want_recs, recs):
+            assert a.bond_sizes() == b.bond_sizes()
+            assert all(torch.equal(x, y) for x, y in zip(a.mps.cores, b.mps.cores))
+            assert torch.equal(ra, rb)
+    assert len(calls) == 2  # the redone group went through the one-call sweep, not through finish again
