@@ -98,8 +98,8 @@ struct TrdWork {       // per-matrix strides; everything indexed by blockIdx.y
   double* mu;          // [B][n_max] shifts of the inverse iteration: lam with coinciding values spread apart (trd_shift_kernel)
   double* bound;       // [B] Gershgorin bound of T
   double* Z;           // [B][n_max][kp] eigenvectors of T
-  double* lu;          // [B][4][n_max][kp] dl, 1/d, du, du2 of the pivoted factorisations
-  unsigned char* piv;  // [B][n_max][kp]
+  double* lu;          // [B][4][n_max][kp] dl, 1/d (lowest mantissa bit: rows interchanged), du / d, du2 / d of the pivoted factorisations
+  unsigned char* piv;  // [B][n_max][kp] not used any more (the interchange flag rides in 1/d); kept in the layout
   double* Tw;          // [B][t_stride] WY factors of the reflector groups (back-transformation)
   int64_t t_stride;
   double* yb;          // [B][2][kBandMax][lda] band reduction: Y = A V of a panel, by parity of the panel
