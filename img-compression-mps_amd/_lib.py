@@ -114,6 +114,7 @@ SIGNATURES = {
     "ndmps_syevd_topk_vectors_auto_f64": (C.c_int, [C.c_int, p_i64, i64, C.c_double, vp, vp, i64, vp, vp, i64, vp]),
     "ndmps_syevd_topk_recover_f64": (C.c_int, [C.c_int, p_i64, i64, vp, i64, p_int, vp]),
     "ndmps_syevd_topk_set_team": (C.c_int, [C.c_int]),
+    "ndmps_syevd_topk_set_streamed": (C.c_int, [C.c_int]),
     "ndmps_syevd_topk_team_fallbacks": (i64, []),
     "ndmps_syevd_topk_team_slots": (C.c_int, [i64]),
     "ndmps_syevd_topk_note_team_fallback": (C.c_int, []),

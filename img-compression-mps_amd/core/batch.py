@@ -195,12 +195,14 @@ def encode_decode_begin(tensor_list: Sequence, groups: int = None, mode: str = "
     objects of k built while k + 1 runs -- the Python section behind a sweep (ranks back, 32 objects per group) and the
     set-up in front of the next one otherwise leave the GPU idle at every batch boundary (1.2 ms of a 27 ms step at 64
     volumes of 256^3, tools/gap_report.py).  Same kernels in the same order as the one-call form: results are
-    bit-identical.
+    bit-identical -- except for batches of five to eight volumes on MORE than one lane, whose resident tridiagonalisations
+    take 32-column blocks then (ndmps_syevd_topk_set_streamed): equal up to the last bits of the fp64 eigen-solver.
     ``lane`` / ``lanes``: a stream of SMALL batches (one group each) may alternate between ``lanes`` sets of streams --
     batch k on lane k mod lanes -- so that consecutive batches overlap on the GPU the way two groups of one batch do."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
 
+    from .. import _lib
     from .ndmps import NDMPS
 
     tensor_list = list(tensor_list)
@@ -217,10 +219,17 @@ def encode_decode_begin(tensor_list: Sequence, groups: int = None, mode: str = "
     def work(slot):
         idx = parts[slot]
         torch.cuda.set_device(device_index)  # pool threads start on device 0
-        with torch.cuda.stream(streams[slot]):
-            streams[slot].wait_event(ready)  # inputs produced on the caller's stream
-            return NDMPS.from_tensors_begin([tensor_list[i] for i in idx], norm=norm, mode=mode, max_bond=max_bond,
-                                            cutoff=cutoff, reconstruct=reconstruct)
+        lib = _lib.load()
+        # several lanes: this batch shares the GPU with its neighbours -- the solver then sizes small batches' resident
+        # launches for overlap, not for the latency of one batch (per host thread; restored behind the call)
+        was = lib.ndmps_syevd_topk_set_streamed(1 if lanes > 1 else 0)
+        try:
+            with torch.cuda.stream(streams[slot]):
+                streams[slot].wait_event(ready)  # inputs produced on the caller's stream
+                return NDMPS.from_tensors_begin([tensor_list[i] for i in idx], norm=norm, mode=mode, max_bond=max_bond,
+                                                cutoff=cutoff, reconstruct=reconstruct)
+        finally:
+            lib.ndmps_syevd_topk_set_streamed(was)
 
     if pool is None:
         pool = _group_pools.get(len(parts))

@@ -2445,6 +2445,12 @@ constexpr size_t kTailLds = ((size_t)kTail * kTailLd + 4 * kTail) * sizeof(doubl
 
 // the resident launch may be switched off per host thread (the fallback after an abort runs the column launches)
 thread_local int g_team_off = 0;
+// Per host thread: the caller runs a STREAM of batches on several lanes (core/batch.py): small batches then take 32-column
+// blocks (16 workgroups per order-512 matrix, half a turn) instead of the 8-column blocks that are fastest for one batch on
+// an otherwise empty GPU (64 workgroups per matrix: eight matrices fill every slot and take the whole turn) as soon as
+// the narrow launch would need more than half the slots -- the reductions of consecutive batches overlap: 8 volumes of
+// 256^3 per batch 5.98 -> 4.8 - 5.0 ms, 8 x 512^3 (config 3) 23.2 -> 21.6 - 22.1.
+thread_local int g_team_streamed = 0;
 std::atomic<long long> g_team_fallbacks{0};
 std::atomic<int> g_inject_abort{0};
 
@@ -2707,7 +2713,12 @@ int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStre
     int slots = 0;
     NDMPS_TRY(team_slots(slots));
     // one to four matrices: 8-column blocks (64 workgroups per order-512 matrix, one per CU)
-    const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= slots && !getenv("NDMPS_TRD_TEAM_WIDE");
+    // 8-column blocks while they fit the slots -- HALF the slots when the caller keeps several batches in flight (a narrow
+    // launch that takes half a turn leaves room for its neighbours' as well; measured on three lanes, ms per batch of 256^3
+    // volumes, narrow / wide: 1 volume 2.8 / 3.2, 2: 3.2 / 3.4, 4: 3.8 / 3.9, 8: 6.0 / 5.0).  NDMPS_TRD_TEAM_NARROW=1: A/B.
+    const bool streamed = g_team_streamed && !getenv("NDMPS_TRD_TEAM_NARROW");
+    const bool narrow_team = (int64_t)batch * ndmps::ceil_div(n_max, 8) <= (streamed ? slots / 2 : slots) &&
+                             !getenv("NDMPS_TRD_TEAM_WIDE");
     // opt-in, batches that fill more than half the slots (17 order-512 matrices and more): half storage (eig_sym.inc),
     // 8 workgroups per order-512 matrix -- a group of 32 takes one workgroup slot per CU and shares the GPU with the
     // other group's reduction or kernels
@@ -3293,6 +3304,14 @@ extern "C" int ndmps_syevd_topk_recover_f64(int batch, const int64_t* h_n, int64
 extern "C" int ndmps_syevd_topk_set_team(int enabled) {
   const int was = g_team_off ? 0 : 1;
   g_team_off = enabled ? 0 : 1;
+  return was;
+}
+// Per host thread: 1 tells the solver that its caller keeps several batches in flight (see g_team_streamed), 0 that a call is
+// alone on the GPU (the default); returns the previous setting.  Results are independent of it up to the last bits (the two
+// block widths associate their column sums differently).
+extern "C" int ndmps_syevd_topk_set_streamed(int streamed) {
+  const int was = g_team_streamed;
+  g_team_streamed = streamed ? 1 : 0;
   return was;
 }
 // number of times a resident launch was given up and its work redone on the column launches (whole process)

@@ -297,6 +297,12 @@ int ndmps_syevd_topk_vectors_f64(int batch, const int64_t* h_n, const int64_t* h
 int ndmps_syevd_topk_recover_f64(int batch, const int64_t* h_n, int64_t k_max, void* d_ws, int64_t ws_bytes,
                                  int* h_recovered, ndmps_stream_t stream);
 int ndmps_syevd_topk_set_team(int enabled);
+/* Per host thread: 1 = the caller keeps several batches in flight on different streams (core/batch.py lanes): batches of five
+ * to eight order-512 matrices then use 32-column blocks -- a quarter of the workgroup slots and half a turn, so the
+ * reductions of consecutive batches overlap -- instead of the 8-column blocks that are fastest for ONE batch on an empty GPU
+ * (one to four matrices keep them: their narrow launch fits half the slots).
+ * Returns the previous setting.  No counterpart in the reference (LAPACK's dgesdd inside quimb, core/ndmps.py:74). */
+int ndmps_syevd_topk_set_streamed(int streamed);
 int64_t ndmps_syevd_topk_team_fallbacks(void);
 int ndmps_syevd_topk_team_slots(int64_t order);
 int ndmps_syevd_topk_note_team_fallback(void);

@@ -1130,6 +1130,17 @@ def test_from_tensors_in_two_halves_equals_the_one_call_form(shape, chi, mode, n
         torch.cuda.synchronize()
         assert all(torch.equal(x, y) for x, y in zip(one[1], r))
         assert all(torch.equal(x, y) for a, b in zip(one[0], o) for x, y in zip(a.mps.cores, b.mps.cores))
+    # three lanes, eight volumes per batch: the resident reductions of such batches take 32-column blocks (the solver is
+    # told that batches overlap) -- the same MPS up to the rounding of the fp64 eigen-solver, not bit for bit
+    eight = [dev(synthetic_mri(shape, seed=120 + i)) for i in range(8)]
+    ref8 = hbatch.encode_decode_concurrent(eight, groups=1, mode=mode, norm=norm, max_bond=chi)
+    flight = [hbatch.encode_decode_begin(eight, groups=1, mode=mode, norm=norm, max_bond=chi, lane=k, lanes=3) for k in range(3)]
+    for pend in flight:
+        o, r = pend.result()
+        torch.cuda.synchronize()
+        assert [x.bond_sizes() for x in o] == [x.bond_sizes() for x in ref8[0]]
+        for a, b in zip(ref8[1], r):
+            assert float((a - b).norm() / a.norm()) <= 2e-5
 
 
 def test_streams_create_returns_usable_distinct_streams():
