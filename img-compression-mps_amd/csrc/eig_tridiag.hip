@@ -2727,7 +2727,10 @@ int trd_team_reduce(int batch, int64_t n_max, TrdDesc* desc, TrdWork& w, hipStre
                      (int64_t)batch * ndmps::ceil_div(n_max, 32) > slots / 2;
     w.tail_lower = sym ? 1 : 0;
     const int team_size = sym ? (int)ndmps::ceil_div(ndmps::ceil_div(n_max, 32), 2) : (int)ndmps::ceil_div(n_max, narrow_team ? 8 : 32);
-    const int per_launch = std::max(1, slots / team_size);
+    // NDMPS_TRD_TEAM_HALF=1 (A/B): launches of half the slots (16 order-512 matrices, one workgroup per CU) under a half turn,
+    // so that the reductions of two batches in flight run side by side instead of alternating
+    const bool half_launches = getenv("NDMPS_TRD_TEAM_HALF") != nullptr && !narrow_team && !sym;
+    const int per_launch = std::max(1, (half_launches ? slots / 2 : slots) / team_size);
     const char* xcd_env = getenv("NDMPS_TRD_XCD");
     const bool xcd_placed = xcd_env ? atoi(xcd_env) != 0 : kTeamXcdDefault;
     int inject = g_inject_abort.load();
