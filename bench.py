@@ -722,6 +722,32 @@ def extras_cubes(ctx, line, xs, x, shape, n_vox, group_step, single_step, ms_per
             "read_write_frac": (8 * ng * n_vox / (grp_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS}
         del dense_g
 
+    def streamed_ms(vols, chi, batches=24):
+        """ms per batch of a STREAM of such batches (what a rank of a strong-scaling run sees step after step):
+        encode_decode_begin in the default stream shape (one group, three alternating sets of streams), objects built
+        `lanes` batches later."""
+        n_groups, n_lanes = batch_mod.default_stream_shape(len(vols), min(8 * chi, 512))
+        flight = []
+
+        def go(k):
+            flight.append(batch_mod.encode_decode_begin(vols, groups=n_groups, mode=job["mode"], max_bond=chi, lane=k,
+                                                        lanes=n_lanes))
+            while len(flight) > n_lanes:
+                flight.pop(0).result()
+
+        for k in range(2 * n_lanes):
+            go(k)
+        while flight:
+            flight.pop(0).result()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(batches):
+            go(k)
+        while flight:
+            flight.pop(0).result()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / batches * 1e3
+
     # one lockstep group of 8 on one stream (per-stage device times undisturbed by concurrent groups), a single volume
     n8 = min(8, len(xs))
     group_step(xs[:n8])
@@ -742,6 +768,9 @@ def extras_cubes(ctx, line, xs, x, shape, n_vox, group_step, single_step, ms_per
     torch.cuda.synchronize()
     single_ms = (time.perf_counter() - t0) / 5 * 1e3
     line["single_volume"] = {"ms": single_ms, "Mvoxels_per_s": n_vox / single_ms / 1e3}
+    if ctx["world"] == 1:  # ... and volume after volume (encode_decode_begin on three lanes): what a caller with a queue of them sees
+        one_ms = streamed_ms([x], job["chi"], batches=30)
+        line["single_volume"].update({"ms_per_volume_in_a_stream": one_ms, "Mvoxels_per_s_in_a_stream": n_vox / one_ms / 1e3})
     line["one_group_of_8"] = {"ms": group8_ms, "Mvoxels_per_s": n8 * n_vox / group8_ms / 1e3, "volumes": n8,
                               "stages": {k: {"ms_per_step": v[0] / 3, "launches_per_step": v[1] / 3}
                                          for k, v in timer8.totals_ms().items()}}
@@ -749,32 +778,6 @@ def extras_cubes(ctx, line, xs, x, shape, n_vox, group_step, single_step, ms_per
     # BASELINE config 4's question asked of ONE GPU: 64 volumes in total over 8 GPUs put 8 on each; the best a perfect
     # 8-GPU run can do is t(64 volumes) / t(8 volumes), both measured here on one GPU.  Not a measured scaling curve.
     if job["config"] == "metric" and not args_overridden(args) and ctx["world"] == 1 and len(xs) >= 64:
-        def streamed_ms(vols, chi, batches=24):
-            """ms per batch of a STREAM of such batches (what a rank of a strong-scaling run sees step after step):
-            encode_decode_begin on default_lanes() alternating sets of streams, objects built `lanes` batches later."""
-            n_groups = batch_mod.default_groups(len(vols))
-            n_lanes = batch_mod.default_lanes(n_groups, min(8 * chi, 512))
-            flight = []
-
-            def go(k):
-                flight.append(batch_mod.encode_decode_begin(vols, groups=n_groups, mode="Std", max_bond=chi, lane=k,
-                                                            lanes=n_lanes))
-                while len(flight) > n_lanes:
-                    flight.pop(0).result()
-
-            for k in range(2 * n_lanes):
-                go(k)
-            while flight:
-                flight.pop(0).result()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(batches):
-                go(k)
-            while flight:
-                flight.pop(0).result()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / batches * 1e3
-
         s8 = streamed_ms(xs[:n8], job["chi"])
         proj = {"256^3 chi=64": {"ms_64_volumes": ms_per_step, "ms_8_volumes": group8_ms, "ratio": ms_per_step / group8_ms,
                                  "ms_8_volumes_streamed": s8, "ratio_streamed": ms_per_step / s8}}
