@@ -238,6 +238,29 @@ def encode_decode_begin(tensor_list: Sequence, groups: int = None, mode: str = "
     return PendingBatch(list(pool.map(work, range(len(parts)))), reconstruct)
 
 
+def encode_decode_stream(batches, groups: int = None, lanes: int = None, mode: str = "Std", norm: bool = False, max_bond=None,
+                         cutoff: float = 1e-10, reconstruct: bool = True, pool=None):
+    """Generator over an iterable of batches (lists of same-shape device volumes; what a dataset driver's loop over chunks
+    of its list produces, evaluation/benchmark.py:58-100): yields ``(objects, reconstructions)`` per batch, in input order.
+    Batch k is enqueued on lane k mod ``lanes`` (``encode_decode_begin``) before the result of batch k - lanes is asked for,
+    so object construction runs under the following batches' kernels and consecutive batches overlap on the GPU;
+    ``groups`` / ``lanes`` default to ``default_stream_shape`` of the first batch.  The reconstructions of a yielded batch may
+    still be being written on its streams: synchronise the device (or the streams) before reading them on the host."""
+    in_flight = []
+    for k, chunk in enumerate(batches):
+        chunk = list(chunk)
+        if groups is None or lanes is None:
+            g0, l0 = default_stream_shape(len(chunk))
+            groups = g0 if groups is None else groups
+            lanes = l0 if lanes is None else lanes
+        in_flight.append(encode_decode_begin(chunk, groups=groups, mode=mode, norm=norm, max_bond=max_bond, cutoff=cutoff,
+                                             reconstruct=reconstruct, pool=pool, lane=k, lanes=lanes))
+        while len(in_flight) > lanes:
+            yield in_flight.pop(0).result()
+    while in_flight:
+        yield in_flight.pop(0).result()
+
+
 def conv_to_tensors(mps_list: Sequence, as_torch: bool = False):
     """benchmark.py:80-100: reconstruct every NDMPS of the (local) list."""
     from .ndmps import NDMPS

@@ -1130,6 +1130,16 @@ def test_from_tensors_in_two_halves_equals_the_one_call_form(shape, chi, mode, n
         torch.cuda.synchronize()
         assert all(torch.equal(x, y) for x, y in zip(one[1], r))
         assert all(torch.equal(x, y) for a, b in zip(one[0], o) for x, y in zip(a.mps.cores, b.mps.cores))
+    # the generator form: batches in, (objects, reconstructions) out, in input order
+    chunks = [vols[:4], vols[1:5], vols[:2]]
+    seen = 0
+    for (o, r), chunk in zip(hbatch.encode_decode_stream(iter(chunks), mode=mode, norm=norm, max_bond=chi), chunks):
+        torch.cuda.synchronize()
+        want = NDMPS.from_tensors(chunk, mode=mode, norm=norm, max_bond=chi, reconstruct=True)
+        assert len(o) == len(chunk) and all(torch.equal(a, b) for a, b in zip(want[1], r))
+        assert all(torch.equal(x, y) for a, b in zip(want[0], o) for x, y in zip(a.mps.cores, b.mps.cores))
+        seen += 1
+    assert seen == 3 and list(hbatch.encode_decode_stream([], max_bond=chi)) == []
     # three lanes, eight volumes per batch: the resident reductions of such batches take 32-column blocks (the solver is
     # told that batches overlap) -- the same MPS up to the rounding of the fp64 eigen-solver, not bit for bit
     eight = [dev(synthetic_mri(shape, seed=120 + i)) for i in range(8)]
