@@ -33,11 +33,44 @@ def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
 
 def conv_to_mps(tensor_list: Sequence, mode: str = "DCT", norm: bool = False, max_bond=None,
                 cutoff: float = 1e-10, device=None):
-    """benchmark.py:58-77: encode every tensor of the (local) list (default mode "DCT" as there)."""
+    """benchmark.py:58-77: encode every tensor of the (local) list (default mode "DCT" as there).  The reference loops
+    volume by volume; a list of same-shape tensors goes through the lockstep path in chunks of up to 64 volumes, chunk after
+    chunk as a stream (``NDMPS.from_tensors_begin`` on three alternating streams: the objects of a chunk are built while the
+    next ones run) -- results equal ``from_tensor`` on each up to the rounding of the fp64 eigen-solver, the order of the
+    list is kept.  Lists of mixed shapes keep the loop."""
+    import numpy as np
+
     from .ndmps import NDMPS
 
-    return [NDMPS.from_tensor(t, norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff, device=device)
-            for t in tensor_list]
+    tensor_list = list(tensor_list)
+    shapes = {tuple(np.shape(t)) for t in tensor_list}
+    if len(tensor_list) < 2 or len(shapes) != 1 or () in shapes:
+        return [NDMPS.from_tensor(t, norm=norm, mode=mode, max_bond=max_bond, cutoff=cutoff, device=device)
+                for t in tensor_list]
+    import torch
+
+    numel = int(np.prod(next(iter(shapes))))
+    chunk = int(max(1, min(64, (8 << 30) // (4 * numel))))  # at most 8 GiB of fp32 volumes in a chunk
+    _, lanes = default_stream_shape(chunk)
+    streams = group_streams(lanes)
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    out, in_flight = [], []
+    for k, i0 in enumerate(range(0, len(tensor_list), chunk)):
+        stream = streams[k % lanes]
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)  # inputs produced on the caller's stream
+            in_flight.append((NDMPS.from_tensors_begin(tensor_list[i0:i0 + chunk], norm=norm, mode=mode, max_bond=max_bond,
+                                                       cutoff=cutoff, device=device), stream))
+        while len(in_flight) > lanes:
+            out.extend(in_flight.pop(0)[0].result())
+    for pending, stream in in_flight:
+        out.extend(pending.result())
+        stream.synchronize()  # like the loop, the call returns with everything done on the device
+    for s in streams:
+        s.synchronize()
+    return out
 
 
 def default_groups(n_items: int) -> int:
