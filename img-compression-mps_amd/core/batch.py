@@ -49,8 +49,19 @@ def conv_to_mps(tensor_list: Sequence, mode: str = "DCT", norm: bool = False, ma
                 for t in tensor_list]
     import torch
 
-    numel = int(np.prod(next(iter(shapes))))
+    shape = next(iter(shapes))
+    numel = int(np.prod(shape))
     chunk = int(max(1, min(64, (8 << 30) // (4 * numel))))  # at most 8 GiB of fp32 volumes in a chunk
+    # ... and a sweep workspace of at most 24 GiB: an exact sweep (no bond cap, the reference's default) solves eigenproblems
+    # of the full bond dimensions -- order 4096 in the middle of a 256^3 volume -- and asks for gigabytes per volume
+    from .. import _lib
+    from .ndmps import _plan_for
+
+    lib = _lib.load()
+    dims = [int(q) for q in _plan_for(tuple(int(v) for v in shape), torch.cuda.current_device()).qubit_size]
+    per_volume = int(lib.ndmps_tt_sweep_batched_workspace_bytes(1, len(dims), _lib.i64_array(dims), int(max_bond or 0)))
+    if per_volume > 0:
+        chunk = int(max(1, min(chunk, (24 << 30) // per_volume)))
     _, lanes = default_stream_shape(chunk)
     streams = group_streams(lanes)
     main = torch.cuda.current_stream()
