@@ -16,6 +16,7 @@ reference switches over); their bodies are this repo's own.  The reference's dat
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence
 
 import numpy as np
@@ -313,11 +314,39 @@ def conv_to_tensors(mps_list: Sequence, as_torch: bool = False):
 
 
 def compress_list(mps_list: Sequence, cutoff: float, max_bond=None) -> None:
-    """benchmark.py:103-118: in-place truncation of every NDMPS of the (local) list."""
+    """benchmark.py:103-118: in-place truncation of every NDMPS of the (local) list.  A compress reads its ranks back bond by
+    bond (a host round trip per bond), but the objects of a list are independent: from two device objects on they are dealt to
+    three host threads with a stream each, so one object's eigen-decompositions run under another's products and host reads
+    (same calls on the same operands per object: the result of each is what the loop gives)."""
     if cutoff is None:
         raise ValueError("compression_factors must not be None")
-    for m in mps_list:
-        m.compress(cutoff, max_bond=max_bond)
+    mps_list = list(mps_list)
+    lanes = min(3, len(mps_list))
+    if lanes < 2 or os.environ.get("NDMPS_COMPRESS_LIST_SERIAL"):
+        for m in mps_list:
+            m.compress(cutoff, max_bond=max_bond)
+        return
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    device_index = torch.cuda.current_device()
+    streams = group_streams(lanes)
+
+    def work(slot):
+        torch.cuda.set_device(device_index)  # pool threads start on device 0
+        with torch.cuda.stream(streams[slot]):
+            streams[slot].wait_event(ready)  # cores produced on the caller's stream
+            for m in mps_list[slot::lanes]:
+                m.compress(cutoff, max_bond=max_bond)
+        streams[slot].synchronize()
+
+    pool = _group_pools.get(lanes)
+    if pool is None:
+        pool = _group_pools.setdefault(lanes, ThreadPoolExecutor(lanes, thread_name_prefix="ndmps-group"))
+    list(pool.map(work, range(lanes)))
 
 
 # ------------------------------------------------------------------ quality-vs-ratio sweep

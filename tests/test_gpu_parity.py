@@ -1790,6 +1790,25 @@ def test_conv_to_mps_streams_a_list_in_chunks_and_keeps_its_order(monkeypatch):
     assert batch.conv_to_mps([]) == [] and len(batch.conv_to_mps(vols[:1])) == 1
 
 
+def test_compress_list_on_three_lanes_equals_the_loop(monkeypatch):
+    """core/batch.compress_list (evaluation/benchmark.py:103-118) deals the objects of a list to three host threads with a
+    stream each; every object gets the same calls on the same operands as in the reference's loop: cores bit for bit."""
+    from imgcompressionmps_amd.core import batch
+
+    vols = [synthetic_mri((64, 64, 64), seed=400 + i) for i in range(7)]
+    a = batch.conv_to_mps(vols, mode="Std")
+    b = copy.deepcopy(a)
+    batch.compress_list(a, 0.05)
+    monkeypatch.setenv("NDMPS_COMPRESS_LIST_SERIAL", "1")
+    batch.compress_list(b, 0.05)
+    for x, y in zip(a, b):
+        assert x.bond_sizes() == y.bond_sizes() and x.bond_sizes() != [1] * len(x.bond_sizes())
+        assert all(torch.equal(p, q) for p, q in zip(x.mps.cores, y.mps.cores))
+        assert x.norm_value == y.norm_value and np.array_equal(np.asarray(x.boundary_list), np.asarray(y.boundary_list))
+    with pytest.raises(ValueError):
+        batch.compress_list(a, None)
+
+
 def test_run_benchmark_matches_an_oracle_driven_loop():
     """the reference's quality-vs-ratio loop (evaluation/benchmark.py:121-194) over a
     small list of volumes, device path vs the same loop driven with the oracle classes."""
