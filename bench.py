@@ -836,6 +836,27 @@ def extras_cubes(ctx, line, xs, x, shape, n_vox, group_step, single_step, ms_per
 
             once()  # warm-up: allocator, plans
             flow[name] = once()
+        # the same flow through the reference's list functions (evaluation/benchmark.py:58-118: conv_to_mps, compress_list,
+        # conv_to_tensors) on 8 volumes: chunks on three streams, a compress per host thread
+        def list_flow():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            objs = batch_mod.conv_to_mps(xs[:8], mode="Std")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            batch_mod.compress_list(objs, 0.01)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            recs = batch_mod.conv_to_tensors(objs, as_torch=True)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            err = float((recs[0].double() - xs[0].double()).norm() / xs[0].double().norm())
+            return {"volumes": 8, "conv_to_mps_ms_per_volume": (t1 - t0) / 8 * 1e3, "compress_list_0.01_ms_per_volume": (t2 - t1) / 8 * 1e3,
+                    "conv_to_tensors_ms_per_volume": (t3 - t2) / 8 * 1e3, "bonds_after_compress": objs[0].bond_sizes(),
+                    "rel_frobenius_error_after_compress": err, "Mvoxels_per_s": 8 * n_vox / (t3 - t0) / 1e6}
+
+        list_flow()
+        flow["fp32_storage_list_functions"] = list_flow()
         flow["note"] = ("NDMPS.from_tensor(x) with quimb's default cutoff 1e-10 and NO bond cap, compress(0.01), to_tensor -- "
                         "what evaluation/benchmark.py:176-178 does per volume; one 256^3 volume, not part of `value`")
         line["reference_flow"] = flow
