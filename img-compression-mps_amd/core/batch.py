@@ -43,6 +43,9 @@ def conv_to_mps(tensor_list: Sequence, mode: str = "DCT", norm: bool = False, ma
 
     from .ndmps import NDMPS
 
+    from .. import _lib
+
+    _lib.require_device()  # the product never computes on the CPU: the same loud failure as from_tensor
     tensor_list = list(tensor_list)
     shapes = {tuple(np.shape(t)) for t in tensor_list}
     if len(tensor_list) < 2 or len(shapes) != 1 or () in shapes:
@@ -55,7 +58,6 @@ def conv_to_mps(tensor_list: Sequence, mode: str = "DCT", norm: bool = False, ma
     chunk = int(max(1, min(64, (8 << 30) // (4 * numel))))  # at most 8 GiB of fp32 volumes in a chunk
     # ... and a sweep workspace of at most 24 GiB: an exact sweep (no bond cap, the reference's default) solves eigenproblems
     # of the full bond dimensions -- order 4096 in the middle of a 256^3 volume -- and asks for gigabytes per volume
-    from .. import _lib
     from .ndmps import _plan_for
 
     lib = _lib.load()
