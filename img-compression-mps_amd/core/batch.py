@@ -315,19 +315,14 @@ def conv_to_tensors(mps_list: Sequence, as_torch: bool = False):
     return NDMPS.to_tensors(mps_list, as_torch=as_torch)
 
 
-def compress_list(mps_list: Sequence, cutoff: float, max_bond=None) -> None:
-    """benchmark.py:103-118: in-place truncation of every NDMPS of the (local) list.  A compress reads its ranks back bond by
-    bond (a host round trip per bond), but the objects of a list are independent: from two device objects on they are dealt to
-    three host threads with a stream each, so one object's eigen-decompositions run under another's products and host reads
-    (same calls on the same operands per object: the result of each is what the loop gives)."""
-    if cutoff is None:
-        raise ValueError("compression_factors must not be None")
-    mps_list = list(mps_list)
-    lanes = min(3, len(mps_list))
-    if lanes < 2 or os.environ.get("NDMPS_COMPRESS_LIST_SERIAL"):
-        for m in mps_list:
-            m.compress(cutoff, max_bond=max_bond)
-        return
+def _map_on_lanes(fn, items, lanes: int = 3):
+    """``[fn(item) for item in items]`` with the items dealt round robin to ``lanes`` host threads that have a HIP stream each
+    (the group streams): what one item's calls leave idle -- host reads of ranks or metrics, small launches, gzip on the CPU --
+    is filled by the others'.  Fewer than two items, or NDMPS_LIST_SERIAL=1: the plain loop on the caller's stream."""
+    items = list(items)
+    lanes = min(int(lanes), len(items))
+    if lanes < 2 or os.environ.get("NDMPS_LIST_SERIAL") or os.environ.get("NDMPS_COMPRESS_LIST_SERIAL"):
+        return [fn(item) for item in items]
     import torch
     from concurrent.futures import ThreadPoolExecutor
 
@@ -336,19 +331,31 @@ def compress_list(mps_list: Sequence, cutoff: float, max_bond=None) -> None:
     ready.record(main)
     device_index = torch.cuda.current_device()
     streams = group_streams(lanes)
+    results = [None] * len(items)
 
     def work(slot):
         torch.cuda.set_device(device_index)  # pool threads start on device 0
         with torch.cuda.stream(streams[slot]):
-            streams[slot].wait_event(ready)  # cores produced on the caller's stream
-            for m in mps_list[slot::lanes]:
-                m.compress(cutoff, max_bond=max_bond)
+            streams[slot].wait_event(ready)  # operands produced on the caller's stream
+            for idx in range(slot, len(items), lanes):
+                results[idx] = fn(items[idx])
         streams[slot].synchronize()
 
     pool = _group_pools.get(lanes)
     if pool is None:
         pool = _group_pools.setdefault(lanes, ThreadPoolExecutor(lanes, thread_name_prefix="ndmps-group"))
     list(pool.map(work, range(lanes)))
+    return results
+
+
+def compress_list(mps_list: Sequence, cutoff: float, max_bond=None) -> None:
+    """benchmark.py:103-118: in-place truncation of every NDMPS of the (local) list.  A compress reads its ranks back bond by
+    bond (a host round trip per bond), but the objects of a list are independent: from two objects on they are dealt to
+    three host threads with a stream each (``_map_on_lanes``), so one object's eigen-decompositions run under another's
+    products and host reads (same calls on the same operands per object: the result of each is what the loop gives)."""
+    if cutoff is None:
+        raise ValueError("compression_factors must not be None")
+    _map_on_lanes(lambda m: m.compress(cutoff, max_bond=max_bond), mps_list)
 
 
 # ------------------------------------------------------------------ quality-vs-ratio sweep
@@ -414,8 +421,8 @@ def benchmark_metric(mps_list, reference_list=None, metric="compression_ratio", 
         raise IndexError("Length mismatch: reference_list and mps_list must have the same length.")
     refs = reference_list if reference_list else [None] * len(mps_list)
     as_mps = metric in _NEEDS_ORIGINAL_MPS
-    return [quality_record(m, None if as_mps else r, r if as_mps else None, dtype, (metric,))[metric]
-            for m, r in zip(mps_list, refs)]
+    return _map_on_lanes(lambda mr: quality_record(mr[0], None if as_mps else mr[1], mr[1] if as_mps else None, dtype,
+                                                   (metric,))[metric], list(zip(mps_list, refs)))
 
 
 def run_benchmark(mps_list, original_tensors_list, cutoff_list, verbose=True, dtype=np.uint16):
@@ -428,8 +435,9 @@ def run_benchmark(mps_list, original_tensors_list, cutoff_list, verbose=True, dt
     stages = []
 
     def take_stage():
-        stages.append([quality_record(m, x, m0, dtype)
-                       for m, x, m0 in zip(mps_list, original_tensors_list, untouched)])
+        # the volumes of a stage are independent: three at a time (reconstruction, SSIM / PSNR with their host reads, gzip)
+        stages.append(_map_on_lanes(lambda t: quality_record(t[0], t[1], t[2], dtype),
+                                    list(zip(mps_list, original_tensors_list, untouched))))
 
     take_stage()
     for n, cutoff in enumerate(cutoff_list, 1):
